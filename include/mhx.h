@@ -1,0 +1,238 @@
+/*
+ * mhx.h -- C ABI of libmhx, the MI355X-native batched Metropolis-Hastings engine.
+ *
+ * This is the drop-in boundary for ONE path of afranson/Lisp-MCMC: everything
+ * `walker-adaptive-steps` does per step, batched over many independent walkers
+ * ("chains").  The reference has no FFI of its own (it is 100 % Common Lisp); the
+ * boundary is the exported Lisp surface listed below, and each entry point here
+ * names the reference function(s) whose work it takes over.  Citations are
+ * file:line under the reference checkout, `M:` = mcmc-fitting.lisp.
+ *
+ *   walker-create              M:1132-1163   -> mhx_create + mhx_set_function /
+ *                                               mhx_set_dataset / mhx_set_bounds +
+ *                                               mhx_init_chains
+ *   walker-make-step           M:1067-1070   -> mhx_logpost
+ *   walker-take-step           M:1072-1095   -> mhx_step_injected (caller's z,u) and the
+ *                                               body of mhx_adaptive_advance (Philox z,u)
+ *   walker-adaptive-steps-full M:862-942     -> mhx_adaptive_begin / _advance / _steps_full
+ *   walker-adaptive-steps      M:946-947     -> mhx_adaptive_steps
+ *   walker-many-steps          M:849-853     -> mhx_many_steps
+ *   walker-get                 M:487-543     -> mhx_get_state / _acceptance / _lmatrix /
+ *                                               _trace / _forward_count
+ *   mfit-walker-estop          M:860-861     -> mhx_request_stop
+ *
+ * Conventions: every function returns MHX_OK (0) or a negative MHX_E* code and never
+ * throws; the message of the last failure on the calling thread is available from
+ * mhx_last_error().  All arrays are caller-allocated, caller-owned, dense row-major
+ * IEEE binary64 / int32 HOST buffers; the engine owns its device memory and copies
+ * in/out synchronously.  One handle is not thread-safe (the reference is single
+ * threaded); distinct handles are independent.  No torch / C++ types appear here.
+ */
+#ifndef MHX_H
+#define MHX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHX_VERSION 100 /* 0.1.0 */
+
+/* ---- limits ------------------------------------------------------------ */
+#define MHX_MAX_PARAMS 64    /* d: length of the shared parameter vector            */
+#define MHX_MAX_FUNCTIONS 16 /* K: functions / datasets of one (global) fit         */
+#define MHX_MAX_FN_PARAMS 32 /* parameters one function gathers from the vector      */
+#define MHX_MAX_BOUNDS 64    /* bounds in one prior-bounds-let block                */
+
+/* ---- status codes ------------------------------------------------------ */
+enum {
+  MHX_OK = 0,
+  MHX_EINVAL = -1,   /* bad argument (message says which)                          */
+  MHX_ENOMEM = -2,   /* host or device allocation failed                           */
+  MHX_EDEVICE = -3,  /* a HIP call failed / no usable gfx950 device                */
+  MHX_ESTATE = -4,   /* call out of order (e.g. stepping before mhx_init_chains)   */
+  MHX_EUNSUPPORTED = -5,
+  MHX_ECOMM = -6     /* collective hook failed                                     */
+};
+
+/* ---- model designators ----------------------------------------------------
+ * The reference's :function is a Lisp closure (lambda (x &key ... &allow-other-keys))
+ * (M:1134-1137) that cannot cross to the GPU; the boundary takes an enumerated device
+ * model plus an index map into the shared parameter vector (global fits share
+ * parameters through one plist, README "Global Parameter Fitting").  Local parameter j
+ * of function k is theta[param_index[j]].  `shape` carries the model's integer shape.
+ *
+ *  POLY          p = n_index;            f = c0 + c1 x + ... (Horner)
+ *  GAUSS_PEAKS   shape = {nbg, npk};     f = bg(x) + sum_p A_p exp(-((x-mu_p)/w_p)^2)
+ *                local order: bg_0..bg_{nbg-1}, then (A, mu, w) per peak
+ *  LORENTZ_PEAKS shape = {nbg, npk};     f = bg(x) + sum_p A_p / (1 + ((x-mu_p)/w_p)^2)
+ *  LORDER_MIXED  6 params scale, linewidth, x0, mix, bg0, bg1 (test.lisp:16-17 names)
+ *                u=(x-x0)/linewidth; f = scale*(cos(mix)*(-2u) + sin(mix)*(1-u^2))/(1+u^2)^2
+ *                                        + bg0 + bg1*x
+ *  EXP_DECAY     3 params A, tau, c;     f = A exp(-x/tau) + c
+ *  SINUSOID      4 params A, omega, phi, c;  f = A sin(omega x + phi) + c
+ *  PVOIGT2       11 params A, b0, b1, mu1, w1, eta1, mu2, w2, eta2, rho, c2
+ *                pv(x;mu,w,eta) = eta/(1+u^2) + (1-eta) exp(-u^2), u=(x-mu)/w
+ *                f = b0 + b1 x + c2 x^2 + A (pv1 + rho pv2)
+ */
+enum {
+  MHX_MODEL_POLY = 0,
+  MHX_MODEL_GAUSS_PEAKS = 1,
+  MHX_MODEL_LORENTZ_PEAKS = 2,
+  MHX_MODEL_LORDER_MIXED = 3,
+  MHX_MODEL_EXP_DECAY = 4,
+  MHX_MODEL_SINUSOID = 5,
+  MHX_MODEL_PVOIGT2 = 6,
+  MHX_MODEL__COUNT = 7
+};
+
+/* ---- likelihood kinds (what the reference's :log-liklihood closure computes) */
+enum {
+  MHX_LIK_NORMAL = 0,        /* log-liklihood-normal (+ README weighted form) M:393-400 */
+  MHX_LIK_NORMAL_CUTOFF = 1, /* log-liklihood-normal-cutoff, each term >= -5000 M:419-427 */
+  MHX_LIK_POISSON = 2        /* log-poisson over points, M:379-383 via M:402-416      */
+};
+
+/* ---- adaptation modes --------------------------------------------------- */
+enum {
+  MHX_ADAPT_FAITHFUL = 0, /* per-walker rule of M:888-942, no collective              */
+  MHX_ADAPT_POOLED = 1    /* extension: forward-step displacement statistics pooled
+                             over all chains (and ranks) every 200 steps              */
+};
+
+/* ---- per-chain status (mhx_get_chain_status) ----------------------------- */
+enum {
+  MHX_CHAIN_RUNNING = 0,
+  MHX_CHAIN_DONE = 1,          /* loop index reached n (M:904)                        */
+  MHX_CHAIN_FP_TRAP = 2,       /* reference would have signalled an unhandled float
+                                  trap (invalid/overflow outside the handler-case of
+                                  M:891-894): the walker is frozen where it stood     */
+  MHX_CHAIN_STOPPED = 3        /* mfit-walker-estop seen                              */
+};
+
+typedef struct mhx_engine mhx_engine;
+
+/* Engine-wide configuration.  Zero-initialise, then set fields; 0 means "default". */
+typedef struct mhx_config {
+  int64_t n_chains;        /* walkers on THIS engine (one engine per GPU/rank)        */
+  int32_t n_params;        /* d                                                        */
+  int32_t n_functions;     /* K (1 for an ordinary fit)                                */
+  int32_t device;          /* HIP device ordinal                                        */
+  int32_t adapt_mode;      /* MHX_ADAPT_*                                               */
+  uint64_t seed;           /* Philox key                                                */
+  int64_t chain_offset;    /* global id of local chain 0 (multi-GPU sharding): the
+                              Philox counter uses global ids, so results do not
+                              depend on how chains are partitioned                      */
+  int32_t history_capacity;/* steps of (prob, theta) kept per chain (ring).  0 ->
+                              1024 = enough for every window the controller reads
+                              (acceptance 1000, settle 10*max(50,d)); the reference
+                              keeps everything (M:549) - set >= n to do the same       */
+  int32_t poisson_logfact_double; /* 0: log-factorial summed in single floats as
+                              M:379-380 does; 1: lgamma in binary64                    */
+} mhx_config;
+
+/* Options of one walker-adaptive-steps-full call (M:862).  Defaults of the Lisp
+ * lambda list are applied by mhx_run_opts_default(). */
+typedef struct mhx_run_opts {
+  int64_t n;               /* :n, default 100000 (walker-adaptive-steps passes 30000)  */
+  double temperature;      /* :temperature, default 1d3 (walker-adaptive-steps: 10)    */
+  int32_t auto_mode;       /* :auto  0 = nil, 1 = :prob-settle (:slope-settle is
+                              outside the path)                             */
+  int64_t max_walker_length; /* :max-walker-length, 0 = nil                            */
+  const double* l_matrix;  /* :l-matrix, d*d row-major, NULL = nil                     */
+  int32_t l_matrix_per_chain; /* 1: l_matrix holds n_chains matrices                   */
+} mhx_run_opts;
+
+/* Collective hook for MHX_ADAPT_POOLED on several ranks: sum `n` doubles in place
+ * over all ranks.  `buf` is a DEVICE pointer when device_buffer != 0 (RCCL path),
+ * else a host pointer.  Return 0 on success. */
+typedef int (*mhx_allreduce_fn)(void* ctx, double* buf, size_t n, int device_buffer);
+
+/* ---- lifecycle ----------------------------------------------------------- */
+int mhx_version(void);
+const char* mhx_last_error(void);
+int mhx_device_count(int* count);
+int mhx_create(const mhx_config* cfg, mhx_engine** out);
+void mhx_destroy(mhx_engine* e);
+
+/* ---- problem definition (walker-create, M:1132-1163) ---------------------- */
+/* Function k: device model + gather map (param_index[j] in [0,d) ).               */
+int mhx_set_function(mhx_engine* e, int k, int model_id, const int32_t* shape, int n_shape,
+                     const int32_t* param_index, int n_index);
+/* Dataset k in the layout clean-data/clean-data-error produce (M:774-825): x, y and a
+ * per-point sigma (sigma == NULL -> 1.0 everywhere, the (or data-error 1) of M:1144).
+ * The engine copies.  For MHX_LIK_POISSON y holds the counts k_i and sigma is ignored. */
+int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y,
+                    const double* sigma, size_t n, int likelihood);
+/* prior-bounds-let block of function k (M:346-369): idx[i] < 0 means "key absent from
+ * the plist" (getf default 0d0, M:353).  n == 0 -> log-prior-flat (M:340-343). */
+int mhx_set_bounds(mhx_engine* e, int k, const int32_t* idx, const double* lo,
+                   const double* hi, int n);
+/* First step of every chain (M:1148-1150): theta0 is [n_chains][d], or [d] when
+ * broadcast != 0.  Resets history, age, length, most-likely step. */
+int mhx_init_chains(mhx_engine* e, const double* theta0, int broadcast);
+
+/* ---- pure evaluation / injected-randomness parity hooks -------------------- */
+/* walker-make-step's prob for n arbitrary parameter vectors theta[n][d] (M:1067-1070).
+ * parts (optional, [n][2]) receives the likelihood sum and the prior sum. */
+int mhx_logpost(mhx_engine* e, const double* theta, size_t n, double* out, double* parts);
+/* One walker-take-step per chain (M:1072-1095) with the caller's randomness:
+ * L  [d][d] (per_chain_l == 0) or [n_chains][d][d];  z [n_chains][d] standard normals
+ * (what alexandria:gaussian-random would have returned, M:687);  u [n_chains] the
+ * (random 1.0d0) of M:1092;  T [n_chains] temperatures.  accepted_out (optional)
+ * receives 1 where the proposal was taken. */
+int mhx_step_injected(mhx_engine* e, const double* L, int per_chain_l, const double* z,
+                      const double* u, const double* T, uint8_t* accepted_out);
+
+/* ---- the controller (walker-adaptive-steps-full, M:862-942) ---------------- */
+void mhx_run_opts_default(mhx_run_opts* o);
+/* Everything before the do loop: schedule, steps-to-settle, initial L (M:866-901). */
+int mhx_adaptive_begin(mhx_engine* e, const mhx_run_opts* o);
+/* Run up to max_iters iterations of the do loop (M:902-942) for every chain that is
+ * still running; *n_running (optional) receives how many chains have not finished. */
+int mhx_adaptive_advance(mhx_engine* e, int64_t max_iters, int64_t* n_running);
+/* begin + advance until every chain is done or mhx_request_stop was called. */
+int mhx_adaptive_steps_full(mhx_engine* e, const mhx_run_opts* o);
+/* (walker-adaptive-steps w n): n, :temperature 10, :auto :prob-settle (M:946-947). */
+int mhx_adaptive_steps(mhx_engine* e, int64_t n);
+/* walker-many-steps (M:849-853): n steps with a constant L, temperature 1.
+ * L == NULL -> diag(1e-2 * median-params) is NOT reproduced; pass L. */
+int mhx_many_steps(mhx_engine* e, int64_t n, const double* L, int per_chain_l);
+int mhx_request_stop(mhx_engine* e);
+
+/* Multi-rank pooled adaptation: install the all-reduce used every adaptation tick. */
+int mhx_set_allreduce(mhx_engine* e, mhx_allreduce_fn fn, void* ctx, int wants_device_buffer);
+
+/* ---- read-back (walker-get, M:487-543) ------------------------------------ */
+/* Any pointer may be NULL.  theta/best_theta [n_chains][d]; others [n_chains]. */
+int mhx_get_state(mhx_engine* e, double* theta, double* logpost, double* best_theta,
+                  double* best_logpost, int64_t* length, int64_t* age);
+int mhx_get_chain_status(mhx_engine* e, int32_t* status, int64_t* loop_index);
+int mhx_get_lmatrix(mhx_engine* e, double* L /* [n_chains][d][d] */);
+int mhx_get_temperature(mhx_engine* e, double* T /* [n_chains] */);
+/* (walker-get w :get :acceptance :take take) for every chain, as a double. */
+int mhx_get_acceptance(mhx_engine* e, int take, double* out);
+/* Newest-first steps of one chain, as (walker-get w :get :steps :take take):
+ * prob[take], theta[take][d]; *n_out = steps actually available. */
+int mhx_get_trace(mhx_engine* e, int64_t chain, int take, double* prob, double* theta,
+                  int* n_out);
+/* (walker-get w :get :l-matrix :take take) of one chain recomputed on the host from the
+ * device trace: status 0 ok, 1 caught error (type-error/div0/overflow -> fallback in
+ * M:891-894), 2 uncaught invalid-operation.  n_forward = (length :forward-steps). */
+int mhx_get_proposal_factor(mhx_engine* e, int64_t chain, int take, double* L_out,
+                            int* status, int* n_forward);
+
+/* Total chain-steps taken by this engine since creation (all chains). */
+int mhx_get_counters(mhx_engine* e, uint64_t* chain_steps, uint64_t* kernel_launches);
+
+/* Timing of the step kernel on the engine's own stream (HIP events): average
+ * milliseconds per launch and launches since the last reset. */
+int mhx_kernel_timing(mhx_engine* e, int reset, double* avg_ms, uint64_t* launches,
+                      double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MHX_H */
