@@ -1,0 +1,115 @@
+"""ctypes binding of libmhx.so -- exactly the entry points include/mhx.h declares.
+
+There is no CPU fallback: if the HIP library is missing or no gfx950 device is usable,
+loading or mhx_create fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmhx.so")
+
+f64p = C.POINTER(C.c_double)
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+u8p = C.POINTER(C.c_uint8)
+u64p = C.POINTER(C.c_uint64)
+
+OK, EINVAL, ENOMEM, EDEVICE, ESTATE, EUNSUPPORTED, ECOMM = 0, -1, -2, -3, -4, -5, -6
+MODEL_POLY, MODEL_GAUSS_PEAKS, MODEL_LORENTZ_PEAKS, MODEL_LORDER_MIXED = 0, 1, 2, 3
+MODEL_EXP_DECAY, MODEL_SINUSOID, MODEL_PVOIGT2 = 4, 5, 6
+LIK_NORMAL, LIK_NORMAL_CUTOFF, LIK_POISSON = 0, 1, 2
+ADAPT_FAITHFUL, ADAPT_POOLED = 0, 1
+CHAIN_RUNNING, CHAIN_DONE, CHAIN_FP_TRAP, CHAIN_STOPPED = 0, 1, 2, 3
+L_OK, L_CAUGHT, L_INVALID, L_EMPTY = 0, 1, 2, 3
+
+
+class Config(C.Structure):
+    _fields_ = [("n_chains", C.c_int64), ("n_params", C.c_int32), ("n_functions", C.c_int32),
+                ("device", C.c_int32), ("adapt_mode", C.c_int32), ("seed", C.c_uint64),
+                ("chain_offset", C.c_int64), ("history_capacity", C.c_int32),
+                ("poisson_logfact_double", C.c_int32)]
+
+
+class RunOpts(C.Structure):
+    _fields_ = [("n", C.c_int64), ("temperature", C.c_double), ("auto_mode", C.c_int32),
+                ("max_walker_length", C.c_int64), ("l_matrix", f64p),
+                ("l_matrix_per_chain", C.c_int32)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, f64p, C.c_size_t, C.c_int)
+
+# name -> (restype, argtypes): every symbol of include/mhx.h
+SIGNATURES = {
+    "mhx_version": (C.c_int, []),
+    "mhx_last_error": (C.c_char_p, []),
+    "mhx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mhx_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "mhx_destroy": (None, [C.c_void_p]),
+    "mhx_set_function": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i32p, C.c_int, i32p, C.c_int]),
+    "mhx_set_dataset": (C.c_int, [C.c_void_p, C.c_int, f64p, f64p, f64p, C.c_size_t, C.c_int]),
+    "mhx_set_bounds": (C.c_int, [C.c_void_p, C.c_int, i32p, f64p, f64p, C.c_int]),
+    "mhx_init_chains": (C.c_int, [C.c_void_p, f64p, C.c_int]),
+    "mhx_logpost": (C.c_int, [C.c_void_p, f64p, C.c_size_t, f64p, f64p]),
+    "mhx_step_injected": (C.c_int, [C.c_void_p, f64p, C.c_int, f64p, f64p, f64p, u8p]),
+    "mhx_run_opts_default": (None, [C.POINTER(RunOpts)]),
+    "mhx_adaptive_begin": (C.c_int, [C.c_void_p, C.POINTER(RunOpts)]),
+    "mhx_adaptive_advance": (C.c_int, [C.c_void_p, C.c_int64, i64p]),
+    "mhx_adaptive_steps_full": (C.c_int, [C.c_void_p, C.POINTER(RunOpts)]),
+    "mhx_adaptive_steps": (C.c_int, [C.c_void_p, C.c_int64]),
+    "mhx_many_steps": (C.c_int, [C.c_void_p, C.c_int64, f64p, C.c_int]),
+    "mhx_request_stop": (C.c_int, [C.c_void_p]),
+    "mhx_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int]),
+    "mhx_get_state": (C.c_int, [C.c_void_p, f64p, f64p, f64p, f64p, i64p, i64p]),
+    "mhx_get_chain_status": (C.c_int, [C.c_void_p, i32p, i64p]),
+    "mhx_get_lmatrix": (C.c_int, [C.c_void_p, f64p]),
+    "mhx_get_temperature": (C.c_int, [C.c_void_p, f64p]),
+    "mhx_get_acceptance": (C.c_int, [C.c_void_p, C.c_int, f64p]),
+    "mhx_get_trace": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, f64p, f64p, C.POINTER(C.c_int)]),
+    "mhx_get_proposal_factor": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, f64p,
+                                          C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mhx_get_counters": (C.c_int, [C.c_void_p, u64p, u64p]),
+    "mhx_kernel_timing": (C.c_int, [C.c_void_p, C.c_int, f64p, u64p, f64p]),
+}
+
+_lib = None
+
+
+class MhxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmhx error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Load libmhx.so (built by lisp-mcmc_amd/csrc/Makefile or __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `make -C lisp-mcmc_amd/csrc` (hipcc, gfx950). "
+                "There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header and library disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise MhxError(rc, lib().mhx_last_error().decode("utf-8", "replace"))
+
+
+def as_f64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(f64p)
+
+
+def as_i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(i32p)

@@ -1,0 +1,351 @@
+// mhx_device.hpp -- gfx950 device code of the walker-adaptive-steps path.
+//
+// Mapping: one wavefront (64 lanes) = one walker ("chain"); the lanes split the data points
+// of the likelihood sum; a workgroup of kWavesPerGroup chains shares LDS-staged data tiles.
+// Everything about one chain (proposal, prior, accept, history, controller) is wave-uniform.
+// Compiled with -ffp-contract=off: every fused multiply-add below is an explicit
+// __builtin_fma, so the proposal / covariance / Cholesky arithmetic keeps the reference's
+// multiply-then-add rounding (M:594, M:643, M:697).
+//
+// M: = mcmc-fitting.lisp of the reference.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mhx_types.hpp"
+
+namespace mhx {
+
+// ------------------------------------------------------------------------------------------
+// wave helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_in_group() {
+  return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+}
+__device__ __forceinline__ double uniform_f64(double v) {
+  long long b = __double_as_longlong(v);
+  int lo = __builtin_amdgcn_readfirstlane((int)b);
+  int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int src_lane /*uniform*/) {
+  long long b = __double_as_longlong(v);
+  int lo = __builtin_amdgcn_readlane((int)b, src_lane);
+  int hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ int64_t uniform_i64(int64_t v) {
+  int lo = __builtin_amdgcn_readfirstlane((int)v);
+  int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((int64_t)hi << 32) | (unsigned int)lo;
+}
+// butterfly sum over the 64 lanes: every lane ends with the same bits
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ bool finite_f64(double v) {
+  return (__double_as_longlong(v) & 0x7ff0000000000000LL) != 0x7ff0000000000000LL;
+}
+
+// ------------------------------------------------------------------------------------------
+// the random stream (specification shared with the oracle; the reference's own stream,
+// cl:random + alexandria:gaussian-random M:687/M:1092, is unseeded and unpinned)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// fdlibm-recipe log on its general path, pure IEEE mul/add/div (bit-identical to the oracle)
+__device__ __forceinline__ double det_log(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+               Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+               Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+               Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  int hx = (int)(b >> 32);
+  unsigned int lx = (unsigned int)b;
+  int k = (hx >> 20) - 1023;
+  hx &= 0x000fffff;
+  int i = (hx + 0x95f64) & 0x100000;
+  unsigned long long nb = ((unsigned long long)(unsigned int)(hx | (i ^ 0x3ff00000)) << 32) | lx;
+  k += (i >> 20);
+  double f = __longlong_as_double((long long)nb) - 1.0;
+  double s = f / (2.0 + f);
+  double dk = (double)k;
+  double z = s * s;
+  double w = z * z;
+  double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  double R = t2 + t1;
+  double hfsq = (0.5 * f) * f;
+  return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+__device__ __forceinline__ double det_ksin(double x) {
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+               S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  double z = x * x;
+  double v = z * x;
+  double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  return x + v * (S1 + z * r);
+}
+__device__ __forceinline__ double det_kcos(double x) {
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+               C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  double z = x * x;
+  double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  return 1.0 - (0.5 * z - z * r);
+}
+__device__ __forceinline__ double det_cos2pi(double t) {
+  double t4 = 4.0 * t;
+  int q = (int)(t4 + 0.5);
+  double r = t4 - (double)q;
+  double y = r * 1.57079632679489661923;
+  double c = det_kcos(y), s = det_ksin(y);
+  switch (q & 3) {
+    case 0: return c;
+    case 1: return -s;
+    case 2: return -c;
+    default: return s;
+  }
+}
+__device__ __forceinline__ unsigned long long bits53(uint32_t a, uint32_t b) {
+  return ((unsigned long long)(a >> 5) << 26) | (unsigned long long)(b >> 6);
+}
+// correctly rounded sqrt (IEEE), so z matches the host's sqrt bit for bit
+__device__ __forceinline__ double ieee_sqrt(double x) { return __dsqrt_rn(x); }
+
+// lane j < d returns z_j; lane 63 returns the accept uniform u in (0,1]; other lanes junk
+__device__ __forceinline__ double rng_lane_value(uint64_t seed, uint64_t gchain, uint64_t draw,
+                                                 int d) {
+  int l = lane_id();
+  uint32_t slot = (l == 63) ? 0xFFFFFFFFu : (uint32_t)l;
+  uint32_t r[4];
+  philox4x32_10((uint32_t)gchain, slot, (uint32_t)draw, (uint32_t)(draw >> 32), (uint32_t)seed,
+                (uint32_t)(seed >> 32), r);
+  double u1 = (double)(bits53(r[0], r[1]) + 1ULL) * 0x1p-53;
+  if (l == 63) return u1;
+  double u2 = (double)bits53(r[2], r[3]) * 0x1p-53;
+  double rad = ieee_sqrt(-2.0 * det_log(u1));
+  (void)d;
+  return rad * det_cos2pi(u2);
+}
+
+// ------------------------------------------------------------------------------------------
+// device models (formula spec: include/mhx.h).  Prep holds wave-uniform values (SGPRs).
+// PF = functor int -> double giving local parameter j of the function (uniform).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double mexp(double s) { return exp(s); }
+
+template <int NBG, int NPK, bool LORENTZ>
+struct PeaksModel {
+  struct Prep {
+    double bg[NBG > 0 ? NBG : 1];
+    double A[NPK], mu[NPK], iw[NPK];
+  };
+  template <class PF>
+  static __device__ __forceinline__ Prep prepare(PF pf, const FnDesc&) {
+    Prep p;
+#pragma unroll
+    for (int j = 0; j < NBG; ++j) p.bg[j] = uniform_f64(pf(j));
+#pragma unroll
+    for (int k = 0; k < NPK; ++k) {
+      p.A[k] = uniform_f64(pf(NBG + 3 * k));
+      p.mu[k] = uniform_f64(pf(NBG + 3 * k + 1));
+      p.iw[k] = uniform_f64(1.0 / pf(NBG + 3 * k + 2));
+    }
+    return p;
+  }
+  static __device__ __forceinline__ double eval(const Prep& p, double x) {
+    double f = 0.0;
+    if (NBG > 0) {
+      f = p.bg[NBG - 1];
+#pragma unroll
+      for (int j = NBG - 2; j >= 0; --j) f = __builtin_fma(f, x, p.bg[j]);
+    }
+#pragma unroll
+    for (int k = 0; k < NPK; ++k) {
+      double t = (x - p.mu[k]) * p.iw[k];
+      double s = t * t;
+      if (LORENTZ)
+        f = f + p.A[k] / (1.0 + s);
+      else
+        f = __builtin_fma(p.A[k], mexp(-s), f);
+    }
+    return f;
+  }
+};
+
+// any (nbg, npk): parameters stay in the wave's LDS slot and are re-read per point
+template <bool LORENTZ>
+struct PeaksModelDyn {
+  struct Prep {
+    const double* q;  // LDS: bg[nbg], then (A, mu, 1/w) per peak
+    int nbg, npk;
+  };
+  template <class PF>
+  static __device__ __forceinline__ Prep prepare(PF pf, const FnDesc& f, double* scratch) {
+    Prep p;
+    p.nbg = f.shape[0];
+    p.npk = f.shape[1];
+    int l = lane_id();
+    int np = p.nbg + 3 * p.npk;
+    if (l < np) {
+      double v = pf(l);
+      bool is_w = l >= p.nbg && ((l - p.nbg) % 3) == 2;
+      scratch[l] = is_w ? 1.0 / v : v;
+    }
+    p.q = scratch;
+    return p;
+  }
+  static __device__ __forceinline__ double eval(const Prep& p, double x) {
+    double f = 0.0;
+    if (p.nbg > 0) {
+      f = p.q[p.nbg - 1];
+      for (int j = p.nbg - 2; j >= 0; --j) f = __builtin_fma(f, x, p.q[j]);
+    }
+    for (int k = 0; k < p.npk; ++k) {
+      const double* q = p.q + p.nbg + 3 * k;
+      double t = (x - q[1]) * q[2];
+      double s = t * t;
+      if (LORENTZ)
+        f = f + q[0] / (1.0 + s);
+      else
+        f = __builtin_fma(q[0], mexp(-s), f);
+    }
+    return f;
+  }
+};
+
+template <int NP>
+struct PolyModel {
+  struct Prep { double c[NP]; };
+  template <class PF>
+  static __device__ __forceinline__ Prep prepare(PF pf, const FnDesc&) {
+    Prep p;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) p.c[j] = uniform_f64(pf(j));
+    return p;
+  }
+  static __device__ __forceinline__ double eval(const Prep& p, double x) {
+    double f = p.c[NP - 1];
+#pragma unroll
+    for (int j = NP - 2; j >= 0; --j) f = __builtin_fma(f, x, p.c[j]);
+    return f;
+  }
+};
+struct PolyModelDyn {
+  struct Prep { const double* c; int np; };
+  template <class PF>
+  static __device__ __forceinline__ Prep prepare(PF pf, const FnDesc& f, double* scratch) {
+    Prep p;
+    p.np = f.n_idx;
+    int l = lane_id();
+    if (l < p.np) scratch[l] = pf(l);
+    p.c = scratch;
+    return p;
+  }
+  static __device__ __forceinline__ double eval(const Prep& p, double x) {
+    if (p.np <= 0) return 0.0;
+    double f = p.c[p.np - 1];
+    for (int j = p.np - 2; j >= 0; --j) f = __builtin_fma(f, x, p.c[j]);
+    return f;
+  }
+};
+
+struct LorderModel {
+  struct Prep { double scale, cm, sm, x0, ilw, bg0, bg1; };
+  template <class PF>
+  static __device__ __forceinline__ Prep prepare(PF pf, const FnDesc&) {
+    Prep p;
+    double mix = pf(3);
+    p.scale = uniform_f64(pf(0));
+    p.cm = uniform_f64(cos(mix));
+    p.sm = uniform_f64(sin(mix));
+    p.x0 = uniform_f64(pf(2));
+    p.ilw = uniform_f64(1.0 / pf(1));
+    p.bg0 = uniform_f64(pf(4));
+    p.bg1 = uniform_f64(pf(5));
+    return p;
+  }
+  static __device__ __forceinline__ double eval(const Prep& p, double x) {
+    double u = (x - p.x0) * p.ilw;
+    double uu = u * u;
+    double q = 1.0 + uu;
+    double num = p.cm * (-2.0 * u) + p.sm * (1.0 - uu);
+    return ((p.scale * num) / (q * q) + p.bg0) + p.bg1 * x;
+  }
+};
+
+struct ExpDecayModel {
+  struct Prep { double A, itau, c; };
+  template <class PF>
+  static __device__ __forceinline__ Prep prepare(PF pf, const FnDesc&) {
+    Prep p;
+    p.A = uniform_f64(pf(0));
+    p.itau = uniform_f64(1.0 / pf(1));
+    p.c = uniform_f64(pf(2));
+    return p;
+  }
+  static __device__ __forceinline__ double eval(const Prep& p, double x) {
+    return __builtin_fma(p.A, mexp(-(x * p.itau)), p.c);
+  }
+};
+
+struct SinusoidModel {
+  struct Prep { double A, om, ph, c; };
+  template <class PF>
+  static __device__ __forceinline__ Prep prepare(PF pf, const FnDesc&) {
+    Prep p;
+    p.A = uniform_f64(pf(0));
+    p.om = uniform_f64(pf(1));
+    p.ph = uniform_f64(pf(2));
+    p.c = uniform_f64(pf(3));
+    return p;
+  }
+  static __device__ __forceinline__ double eval(const Prep& p, double x) {
+    return __builtin_fma(p.A, sin(p.om * x + p.ph), p.c);
+  }
+};
+
+struct PVoigt2Model {
+  struct Prep { double A, b0, b1, mu1, iw1, eta1, mu2, iw2, eta2, rho, c2; };
+  template <class PF>
+  static __device__ __forceinline__ Prep prepare(PF pf, const FnDesc&) {
+    Prep p;
+    p.A = uniform_f64(pf(0)); p.b0 = uniform_f64(pf(1)); p.b1 = uniform_f64(pf(2));
+    p.mu1 = uniform_f64(pf(3)); p.iw1 = uniform_f64(1.0 / pf(4)); p.eta1 = uniform_f64(pf(5));
+    p.mu2 = uniform_f64(pf(6)); p.iw2 = uniform_f64(1.0 / pf(7)); p.eta2 = uniform_f64(pf(8));
+    p.rho = uniform_f64(pf(9)); p.c2 = uniform_f64(pf(10));
+    return p;
+  }
+  static __device__ __forceinline__ double eval(const Prep& p, double x) {
+    double u1 = (x - p.mu1) * p.iw1, u2 = (x - p.mu2) * p.iw2;
+    double s1 = u1 * u1, s2 = u2 * u2;
+    double pv1 = p.eta1 / (1.0 + s1) + (1.0 - p.eta1) * mexp(-s1);
+    double pv2 = p.eta2 / (1.0 + s2) + (1.0 - p.eta2) * mexp(-s2);
+    double bg = __builtin_fma(p.c2, x * x, __builtin_fma(p.b1, x, p.b0));
+    return __builtin_fma(p.A, __builtin_fma(p.rho, pv2, pv1), bg);
+  }
+};
+
+}  // namespace mhx

@@ -1,0 +1,842 @@
+// mhx_engine.cpp -- host side of libmhx: the C ABI of include/mhx.h over the gfx950 kernels.
+//
+// No CPU fallback exists: every numeric entry point launches HIP kernels on the configured
+// device and fails with MHX_EDEVICE when that is impossible.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mhx.h"
+#include "mhx_launch.hpp"
+#include "mhx_types.hpp"
+
+using namespace mhx;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess)                                                               \
+      return fail(MHX_EDEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                  __FILE__, __LINE__);                                                  \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t alloc(size_t count, bool zero = true) {
+    release();
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e != hipSuccess) {
+      p = nullptr;
+      return e;
+    }
+    n = count;
+    if (zero) e = hipMemset(p, 0, count * sizeof(T));
+    return e;
+  }
+};
+
+struct Dataset {
+  DevBuf<double> x, y, w, c;
+  bool set = false;
+};
+
+int64_t steps_to_settle_of(int d) { return 10 * (int64_t)std::max(50, d); }  // M:873
+
+int pow2_ceil(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+}  // namespace
+
+struct mhx_engine {
+  mhx_config cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t stop_stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  ProblemDesc P{};  // host copy; device pointers inside
+  bool fn_set[MHX_MAX_FUNCTIONS] = {};
+  Dataset data[MHX_MAX_FUNCTIONS];
+  DevBuf<ProblemDesc> dP;
+  bool problem_dirty = true;
+  int spec = SPEC_GENERIC;
+
+  ChainState S{};
+  DevBuf<double> theta, prob, best_theta, best_prob, hist_prob, hist_theta, L, temperature,
+      mat_tmp, pool_stats;
+  DevBuf<int64_t> length, age, n_hist, loop_i, reset_index;
+  DevBuf<uint64_t> draw;
+  DevBuf<int32_t> shutting, status, fwd_idx, stop_flag;
+  DevBuf<unsigned long long> step_counter;
+  bool chains_ready = false;
+
+  RunDesc R{};
+  DevBuf<double> temps;
+  bool run_ready = false;
+  int64_t chunk_iters = 64;
+
+  mhx_allreduce_fn allreduce = nullptr;
+  void* allreduce_ctx = nullptr;
+  int allreduce_device = 0;
+
+  // accounting
+  uint64_t launches = 0;
+  double kernel_ms = 0.0;
+  uint64_t timed_launches = 0;
+};
+
+namespace {
+
+int use_device(mhx_engine* e) {
+  HIP_TRY(hipSetDevice(e->device));
+  return MHX_OK;
+}
+
+int finalize_problem(mhx_engine* e) {
+  if (!e->problem_dirty) return MHX_OK;
+  for (int k = 0; k < e->P.K; ++k) {
+    if (!e->fn_set[k]) return fail(MHX_ESTATE, "function %d was never set (mhx_set_function)", k);
+    if (!e->data[k].set) return fail(MHX_ESTATE, "dataset %d was never set (mhx_set_dataset)", k);
+  }
+  HIP_TRY(hipMemcpy(e->dP.p, &e->P, sizeof(ProblemDesc), hipMemcpyHostToDevice));
+  e->spec = select_spec(e->P);
+  if (const char* s = getenv("MHX_FORCE_GENERIC"))
+    if (atoi(s) != 0) e->spec = SPEC_GENERIC;
+  e->problem_dirty = false;
+  return MHX_OK;
+}
+
+int check_model(int model, const int32_t* shape, int n_shape, int n_index) {
+  switch (model) {
+    case MHX_MODEL_POLY:
+      if (n_index < 1) return fail(MHX_EINVAL, "POLY needs >= 1 parameter");
+      return MHX_OK;
+    case MHX_MODEL_GAUSS_PEAKS:
+    case MHX_MODEL_LORENTZ_PEAKS:
+      if (n_shape < 2 || shape[0] < 0 || shape[1] < 0 || shape[0] + 3 * shape[1] != n_index)
+        return fail(MHX_EINVAL, "peaks model: shape {nbg,npk} must satisfy nbg+3*npk == n_index");
+      return MHX_OK;
+    case MHX_MODEL_LORDER_MIXED:
+      return n_index == 6 ? MHX_OK : fail(MHX_EINVAL, "LORDER_MIXED takes 6 parameters");
+    case MHX_MODEL_EXP_DECAY:
+      return n_index == 3 ? MHX_OK : fail(MHX_EINVAL, "EXP_DECAY takes 3 parameters");
+    case MHX_MODEL_SINUSOID:
+      return n_index == 4 ? MHX_OK : fail(MHX_EINVAL, "SINUSOID takes 4 parameters");
+    case MHX_MODEL_PVOIGT2:
+      return n_index == 11 ? MHX_OK : fail(MHX_EINVAL, "PVOIGT2 takes 11 parameters");
+    default:
+      return fail(MHX_EINVAL, "unknown model id %d", model);
+  }
+}
+
+// M:379-380: (reduce (lambda (x y) (+ x (log y))) (up-to n)) sums SINGLE-float logs
+double log_factorial_ref(long n, bool in_double, std::vector<float>& cache) {
+  if (in_double) return std::lgamma((double)n + 1.0);
+  if (n <= 0) return 0.0;
+  if ((long)cache.size() <= n) {
+    size_t old = cache.size();
+    if (old == 0) {
+      cache.push_back(0.0f);
+      old = 1;
+    }
+    cache.resize((size_t)n + 1);
+    for (size_t m = old; m <= (size_t)n; ++m) cache[m] = cache[m - 1] + (float)std::log((double)m);
+  }
+  return (double)cache[(size_t)n];
+}
+
+int alloc_state(mhx_engine* e) {
+  const int64_t C = e->cfg.n_chains;
+  const int d = e->cfg.n_params;
+  const int64_t sts = steps_to_settle_of(d);
+  int want = e->cfg.history_capacity > 0 ? e->cfg.history_capacity : 1024;
+  want = std::max<int>(want, (int)std::max<int64_t>(1000, sts));
+  const int Rcap = pow2_ceil(want);
+  auto& S = e->S;
+  S.n_chains = C;
+  S.chain_offset = e->cfg.chain_offset;
+  S.d = d;
+  S.R = Rcap;
+  S.seed = e->cfg.seed;
+#define ALLOC(buf, count)                                             \
+  if (e->buf.alloc((size_t)(count)) != hipSuccess)                    \
+    return fail(MHX_ENOMEM, "hipMalloc of %s (%zu elements) failed", #buf, (size_t)(count));
+  ALLOC(theta, C * d);
+  ALLOC(prob, C);
+  ALLOC(best_theta, C * d);
+  ALLOC(best_prob, C);
+  ALLOC(length, C);
+  ALLOC(age, C);
+  ALLOC(draw, C);
+  ALLOC(n_hist, C);
+  ALLOC(hist_prob, C * Rcap);
+  ALLOC(hist_theta, C * Rcap * d);
+  ALLOC(L, C * d * d);
+  ALLOC(temperature, C);
+  ALLOC(loop_i, C);
+  ALLOC(reset_index, C);
+  ALLOC(shutting, C);
+  ALLOC(status, C);
+  ALLOC(fwd_idx, C * sts);
+  ALLOC(mat_tmp, C * 2 * d * d);
+  ALLOC(pool_stats, C * (1 + d + d * d));
+  ALLOC(stop_flag, 1);
+  ALLOC(step_counter, 1);
+#undef ALLOC
+  S.theta = e->theta.p;
+  S.prob = e->prob.p;
+  S.best_theta = e->best_theta.p;
+  S.best_prob = e->best_prob.p;
+  S.length = e->length.p;
+  S.age = e->age.p;
+  S.draw = e->draw.p;
+  S.n_hist = e->n_hist.p;
+  S.hist_prob = e->hist_prob.p;
+  S.hist_theta = e->hist_theta.p;
+  S.L = e->L.p;
+  S.temperature = e->temperature.p;
+  S.loop_i = e->loop_i.p;
+  S.reset_index = e->reset_index.p;
+  S.shutting = e->shutting.p;
+  S.status = e->status.p;
+  S.fwd_idx = e->fwd_idx.p;
+  S.mat_tmp = e->mat_tmp.p;
+  S.pool_stats = e->pool_stats.p;
+  S.step_counter = e->step_counter.p;
+  return MHX_OK;
+}
+
+int count_running(mhx_engine* e, int64_t* n_running) {
+  std::vector<int32_t> st((size_t)e->cfg.n_chains);
+  HIP_TRY(hipMemcpy(st.data(), e->status.p, st.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  int64_t r = 0;
+  for (int32_t s : st) r += s == MHX_CHAIN_RUNNING;
+  *n_running = r;
+  return MHX_OK;
+}
+
+// one timed launch of the fused step kernel
+int launch_steps(mhx_engine* e, int64_t iters, int plain) {
+  HIP_TRY(hipEventRecord(e->ev0, e->stream));
+  HIP_TRY(launch_adaptive(e->spec, e->stream, e->dP.p, e->S, e->R, iters, plain));
+  HIP_TRY(hipEventRecord(e->ev1, e->stream));
+  HIP_TRY(hipEventSynchronize(e->ev1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  e->kernel_ms += ms;
+  e->timed_launches++;
+  e->launches++;
+  // keep a launch near 50 ms so the stop flag and the host stay responsive
+  if (ms > 0.f) {
+    double per_iter = ms / (double)iters;
+    int64_t want = (int64_t)(50.0 / std::max(per_iter, 1e-6));
+    e->chunk_iters = std::min<int64_t>(std::max<int64_t>(want, 8), 1 << 16);
+  }
+  return MHX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mhx_version(void) { return MHX_VERSION; }
+const char* mhx_last_error(void) { return g_err.c_str(); }
+
+int mhx_device_count(int* count) {
+  if (!count) return fail(MHX_EINVAL, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(MHX_EDEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return MHX_OK;
+}
+
+int mhx_create(const mhx_config* cfg, mhx_engine** out) {
+  if (!cfg || !out) return fail(MHX_EINVAL, "cfg/out is NULL");
+  *out = nullptr;
+  if (cfg->n_chains < 1) return fail(MHX_EINVAL, "n_chains must be >= 1");
+  if (cfg->n_params < 1 || cfg->n_params > MHX_MAX_PARAMS)
+    return fail(MHX_EINVAL, "n_params must be in [1,%d]", MHX_MAX_PARAMS);
+  if (cfg->n_functions < 1 || cfg->n_functions > MHX_MAX_FUNCTIONS)
+    return fail(MHX_EINVAL, "n_functions must be in [1,%d]", MHX_MAX_FUNCTIONS);
+  if (cfg->adapt_mode != MHX_ADAPT_FAITHFUL && cfg->adapt_mode != MHX_ADAPT_POOLED)
+    return fail(MHX_EINVAL, "adapt_mode");
+  if ((uint64_t)(cfg->chain_offset + cfg->n_chains) > 0xFFFFFFFFull)
+    return fail(MHX_EINVAL, "global chain ids must fit 32 bits (Philox counter word)");
+  int ndev = 0;
+  hipError_t he = hipGetDeviceCount(&ndev);
+  if (he != hipSuccess || ndev <= 0)
+    return fail(MHX_EDEVICE, "no HIP device available (%s): libmhx has no CPU path",
+                he != hipSuccess ? hipGetErrorString(he) : "0 devices");
+  if (cfg->device < 0 || cfg->device >= ndev)
+    return fail(MHX_EINVAL, "device %d out of range (have %d)", cfg->device, ndev);
+  mhx_engine* e = new (std::nothrow) mhx_engine();
+  if (!e) return fail(MHX_ENOMEM, "host allocation failed");
+  e->cfg = *cfg;
+  e->device = cfg->device;
+  int rc = MHX_OK;
+  do {
+    if ((rc = use_device(e)) != MHX_OK) break;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, e->device) != hipSuccess) {
+      rc = fail(MHX_EDEVICE, "hipGetDeviceProperties failed");
+      break;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("MHX_ALLOW_ANY_ARCH")) {
+      rc = fail(MHX_EDEVICE, "device %d is %s; libmhx is built for gfx950 (MI355X) only",
+                e->device, prop.gcnArchName);
+      break;
+    }
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->stop_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) {
+      rc = fail(MHX_EDEVICE, "stream/event creation failed");
+      break;
+    }
+    if (configure_kernels() != hipSuccess) {
+      rc = fail(MHX_EDEVICE, "hipFuncSetAttribute(max dynamic LDS = %zu) failed",
+                group_lds_bytes());
+      break;
+    }
+    if (e->dP.alloc(1) != hipSuccess) {
+      rc = fail(MHX_ENOMEM, "hipMalloc(ProblemDesc) failed");
+      break;
+    }
+    e->P.d = cfg->n_params;
+    e->P.K = cfg->n_functions;
+    if ((rc = alloc_state(e)) != MHX_OK) break;
+    e->R.stop_flag = e->stop_flag.p;
+  } while (0);
+  if (rc != MHX_OK) {
+    std::string keep = g_err;
+    mhx_destroy(e);
+    g_err = keep;
+    return rc;
+  }
+  *out = e;
+  return MHX_OK;
+}
+
+void mhx_destroy(mhx_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  if (e->stop_stream) (void)hipStreamDestroy(e->stop_stream);
+  delete e;
+}
+
+int mhx_set_function(mhx_engine* e, int k, int model_id, const int32_t* shape, int n_shape,
+                     const int32_t* param_index, int n_index) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  if (k < 0 || k >= e->P.K) return fail(MHX_EINVAL, "function index %d out of range", k);
+  if (n_index < 0 || n_index > MHX_MAX_FN_PARAMS || (n_index > 0 && !param_index))
+    return fail(MHX_EINVAL, "n_index must be in [0,%d]", MHX_MAX_FN_PARAMS);
+  if (n_shape < 0 || n_shape > 4 || (n_shape > 0 && !shape)) return fail(MHX_EINVAL, "n_shape");
+  int rc = check_model(model_id, shape, n_shape, n_index);
+  if (rc != MHX_OK) return rc;
+  FnDesc& f = e->P.fn[k];
+  for (int j = 0; j < n_index; ++j) {
+    if (param_index[j] < 0 || param_index[j] >= e->P.d)
+      return fail(MHX_EINVAL, "param_index[%d] = %d outside [0,%d)", j, param_index[j], e->P.d);
+    f.idx[j] = param_index[j];
+  }
+  f.model = model_id;
+  f.n_idx = n_index;
+  for (int i = 0; i < 4; ++i) f.shape[i] = i < n_shape ? shape[i] : 0;
+  e->fn_set[k] = true;
+  e->problem_dirty = true;
+  return MHX_OK;
+}
+
+int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y, const double* sigma,
+                    size_t n, int likelihood) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  if (k < 0 || k >= e->P.K) return fail(MHX_EINVAL, "dataset index %d out of range", k);
+  if (n > 0 && (!x || !y)) return fail(MHX_EINVAL, "x/y is NULL");
+  if (likelihood < MHX_LIK_NORMAL || likelihood > MHX_LIK_POISSON)
+    return fail(MHX_EINVAL, "unknown likelihood %d", likelihood);
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  const size_t nt = (n + kTilePoints - 1) / kTilePoints;
+  const size_t np = std::max<size_t>(nt, 1) * kTilePoints;
+  std::vector<double> hx(np), hy(np), hw(np), hc(np);
+  long double csum = 0.0L;
+  const double half_log_2pi = -0.5 * std::log(2.0 * M_PI);  // (* -1/2 (log (* 2 pi))) M:377
+  std::vector<float> lf_cache;
+  for (size_t i = 0; i < n; ++i) {
+    hx[i] = x[i];
+    hy[i] = y[i];
+    if (likelihood == MHX_LIK_POISSON) {
+      if (!(y[i] >= 0.0) || y[i] != std::floor(y[i]) || y[i] > 1e9)
+        return fail(MHX_EINVAL, "poisson count y[%zu] = %g is not a non-negative integer", i, y[i]);
+      hw[i] = 0.0;
+      hc[i] = 0.0;
+      csum -= (long double)log_factorial_ref((long)y[i], e->cfg.poisson_logfact_double != 0,
+                                             lf_cache);
+    } else {
+      const double s = sigma ? sigma[i] : 1.0;  // (if data-error data-error 1) M:1144
+      if (!(s > 0.0) || !std::isfinite(s))
+        return fail(MHX_EINVAL, "sigma[%zu] = %g must be finite and > 0 (M:376)", i, s);
+      hw[i] = 1.0 / s;
+      hc[i] = half_log_2pi + (-1.0 * std::log(s));  // first two terms of M:377
+      csum += (long double)hc[i];
+    }
+  }
+  for (size_t i = n; i < np; ++i) {  // neutral pads: r = (0 - m) * 0 = 0
+    hx[i] = n ? x[n - 1] : 0.0;
+    hy[i] = 0.0;
+    hw[i] = 0.0;
+    hc[i] = 0.0;
+  }
+  Dataset& D = e->data[k];
+  if (D.x.alloc(np, false) != hipSuccess || D.y.alloc(np, false) != hipSuccess ||
+      D.w.alloc(np, false) != hipSuccess || D.c.alloc(np, false) != hipSuccess)
+    return fail(MHX_ENOMEM, "hipMalloc of dataset %d (%zu points) failed", k, np);
+  HIP_TRY(hipMemcpy(D.x.p, hx.data(), np * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(D.y.p, hy.data(), np * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(D.w.p, hw.data(), np * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(D.c.p, hc.data(), np * sizeof(double), hipMemcpyHostToDevice));
+  FnDesc& f = e->P.fn[k];
+  f.x = D.x.p;
+  f.y = D.y.p;
+  f.w = D.w.p;
+  f.c = D.c.p;
+  f.n = (int64_t)n;
+  f.n_tiles = (int64_t)nt;
+  f.lik = likelihood;
+  f.lik_const = (double)csum;
+  D.set = true;
+  e->problem_dirty = true;
+  return MHX_OK;
+}
+
+int mhx_set_bounds(mhx_engine* e, int k, const int32_t* idx, const double* lo, const double* hi,
+                   int n) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  if (k < 0 || k >= e->P.K) return fail(MHX_EINVAL, "function index %d out of range", k);
+  if (n < 0 || n > MHX_MAX_BOUNDS || (n > 0 && (!idx || !lo || !hi)))
+    return fail(MHX_EINVAL, "n bounds must be in [0,%d]", MHX_MAX_BOUNDS);
+  FnDesc& f = e->P.fn[k];
+  for (int i = 0; i < n; ++i) {
+    if (idx[i] >= e->P.d) return fail(MHX_EINVAL, "bounds idx[%d] = %d outside the vector", i, idx[i]);
+    f.bidx[i] = idx[i] < 0 ? -1 : idx[i];
+    f.blo[i] = lo[i];
+    f.bhi[i] = hi[i];
+  }
+  f.n_bounds = n;
+  e->problem_dirty = true;
+  return MHX_OK;
+}
+
+int mhx_init_chains(mhx_engine* e, const double* theta0, int broadcast) {
+  if (!e || !theta0) return fail(MHX_EINVAL, "engine/theta0 is NULL");
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  if ((rc = finalize_problem(e)) != MHX_OK) return rc;
+  const int64_t C = e->cfg.n_chains;
+  const int d = e->P.d;
+  if (broadcast) {
+    std::vector<double> full((size_t)C * d);
+    for (int64_t c = 0; c < C; ++c) memcpy(&full[(size_t)c * d], theta0, sizeof(double) * d);
+    HIP_TRY(hipMemcpy(e->theta.p, full.data(), full.size() * sizeof(double), hipMemcpyHostToDevice));
+  } else {
+    HIP_TRY(hipMemcpy(e->theta.p, theta0, (size_t)C * d * sizeof(double), hipMemcpyHostToDevice));
+  }
+  HIP_TRY(launch_init(e->spec, e->stream, e->dP.p, e->S));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->launches++;
+  e->chains_ready = true;
+  e->run_ready = false;
+  return MHX_OK;
+}
+
+int mhx_logpost(mhx_engine* e, const double* theta, size_t n, double* out, double* parts) {
+  if (!e || (n > 0 && (!theta || !out))) return fail(MHX_EINVAL, "NULL argument");
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  if ((rc = finalize_problem(e)) != MHX_OK) return rc;
+  if (n == 0) return MHX_OK;
+  const int d = e->P.d;
+  DevBuf<double> dth, dout, dparts;
+  if (dth.alloc(n * d, false) != hipSuccess || dout.alloc(n, false) != hipSuccess ||
+      dparts.alloc(2 * n, false) != hipSuccess)
+    return fail(MHX_ENOMEM, "hipMalloc for %zu parameter vectors failed", n);
+  HIP_TRY(hipMemcpy(dth.p, theta, n * d * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(launch_logpost(e->spec, e->stream, e->dP.p, dth.p, (int64_t)n, dout.p, dparts.p));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->launches++;
+  HIP_TRY(hipMemcpy(out, dout.p, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (parts) HIP_TRY(hipMemcpy(parts, dparts.p, 2 * n * sizeof(double), hipMemcpyDeviceToHost));
+  return MHX_OK;
+}
+
+int mhx_step_injected(mhx_engine* e, const double* L, int per_chain_l, const double* z,
+                      const double* u, const double* T, uint8_t* accepted_out) {
+  if (!e || !L || !z || !u || !T) return fail(MHX_EINVAL, "NULL argument");
+  if (!e->chains_ready) return fail(MHX_ESTATE, "mhx_init_chains has not been called");
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  if ((rc = finalize_problem(e)) != MHX_OK) return rc;
+  const size_t C = (size_t)e->cfg.n_chains, d = (size_t)e->P.d;
+  DevBuf<double> dL, dz, du, dT;
+  DevBuf<unsigned char> dacc;
+  const size_t nL = (per_chain_l ? C : 1) * d * d;
+  if (dL.alloc(nL, false) != hipSuccess || dz.alloc(C * d, false) != hipSuccess ||
+      du.alloc(C, false) != hipSuccess || dT.alloc(C, false) != hipSuccess ||
+      dacc.alloc(C) != hipSuccess)
+    return fail(MHX_ENOMEM, "hipMalloc for injected randomness failed");
+  HIP_TRY(hipMemcpy(dL.p, L, nL * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dz.p, z, C * d * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(du.p, u, C * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dT.p, T, C * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(launch_step_injected(e->spec, e->stream, e->dP.p, e->S, dL.p, per_chain_l, dz.p, du.p,
+                               dT.p, dacc.p));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->launches++;
+  if (accepted_out) HIP_TRY(hipMemcpy(accepted_out, dacc.p, C, hipMemcpyDeviceToHost));
+  return MHX_OK;
+}
+
+void mhx_run_opts_default(mhx_run_opts* o) {
+  if (!o) return;
+  memset(o, 0, sizeof *o);
+  o->n = 100000;         // (n 100000)        M:862
+  o->temperature = 1e3;  // (temperature 1d3) M:862
+  o->auto_mode = 1;      // (auto (or :prob-settle :slope-settle nil)) evaluates to :prob-settle
+}
+
+int mhx_adaptive_begin(mhx_engine* e, const mhx_run_opts* o) {
+  if (!e || !o) return fail(MHX_EINVAL, "NULL argument");
+  if (!e->chains_ready) return fail(MHX_ESTATE, "mhx_init_chains has not been called");
+  if (o->n < 0) return fail(MHX_EINVAL, "n must be >= 0");
+  if (o->auto_mode != 0 && o->auto_mode != 1)
+    return fail(MHX_EUNSUPPORTED, ":slope-settle is outside the accelerated path");
+  if (!(o->temperature > 0.0) || !std::isfinite(o->temperature))
+    return fail(MHX_EINVAL, "temperature must be finite and > 0");
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  if ((rc = finalize_problem(e)) != MHX_OK) return rc;
+  const int d = e->P.d;
+  RunDesc& R = e->R;
+  R.n = o->n;                                       // (floor n) M:866
+  R.sts = steps_to_settle_of(d);                    // M:873
+  R.temp_steps = std::max<int64_t>(R.n, 10 * R.sts);  // M:875
+  R.tail = std::max<int64_t>(2000, R.sts);          // (max 2000 steps-to-settle) M:906, M:917
+  R.auto_mode = o->auto_mode;
+  R.has_mwl = o->max_walker_length > 0;
+  R.mwl = o->max_walker_length / 2;  // (floor max-walker-length 2) M:868
+  R.adapt_mode = e->cfg.adapt_mode;
+  R.stop_flag = e->stop_flag.p;
+  if (R.has_mwl && R.mwl < 1) return fail(MHX_EINVAL, "max_walker_length must be >= 2");
+  // temps M:878: (max 1 (* (cos (* x pi (+ 1 (* 2 (floor temp-steps 5000))) (/ (* 2 temp-steps))))
+  // temperature)), products left to right, the rational factor converted to double
+  std::vector<double> temps((size_t)R.temp_steps);
+  const double kfac = (double)(1 + 2 * (R.temp_steps / 5000));
+  const double inv = 1.0 / (double)(2 * R.temp_steps);
+  for (int64_t x = 0; x < R.temp_steps; ++x) {
+    const double arg = (((double)x * M_PI) * kfac) * inv;
+    const double v = std::cos(arg) * o->temperature;
+    temps[(size_t)x] = v > 1.0 ? v : 1.0;
+  }
+  if (e->temps.alloc(temps.size(), false) != hipSuccess)
+    return fail(MHX_ENOMEM, "hipMalloc(temperature schedule, %zu) failed", temps.size());
+  HIP_TRY(hipMemcpy(e->temps.p, temps.data(), temps.size() * sizeof(double), hipMemcpyHostToDevice));
+  R.temps = e->temps.p;
+  HIP_TRY(hipMemset(e->stop_flag.p, 0, sizeof(int32_t)));  // (setf mfit-walker-estop nil) M:865
+  const size_t C = (size_t)e->cfg.n_chains, dd = (size_t)d * d;
+  if (o->l_matrix) {
+    if (o->l_matrix_per_chain) {
+      HIP_TRY(hipMemcpy(e->L.p, o->l_matrix, C * dd * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+      std::vector<double> full(C * dd);
+      for (size_t c = 0; c < C; ++c) memcpy(&full[c * dd], o->l_matrix, dd * sizeof(double));
+      HIP_TRY(hipMemcpy(e->L.p, full.data(), full.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
+  HIP_TRY(launch_initial_l(e->stream, e->S, R, o->l_matrix ? 1 : 0, o->temperature));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->launches++;
+  e->run_ready = true;
+  return MHX_OK;
+}
+
+int mhx_adaptive_advance(mhx_engine* e, int64_t max_iters, int64_t* n_running) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  if (!e->run_ready) return fail(MHX_ESTATE, "mhx_adaptive_begin has not been called");
+  if (max_iters < 0) return fail(MHX_EINVAL, "max_iters < 0");
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  if (max_iters > 0 && (rc = launch_steps(e, max_iters, 0)) != MHX_OK) return rc;
+  if (n_running) return count_running(e, n_running);
+  return MHX_OK;
+}
+
+int mhx_adaptive_steps_full(mhx_engine* e, const mhx_run_opts* o) {
+  int rc = mhx_adaptive_begin(e, o);
+  if (rc != MHX_OK) return rc;
+  int64_t running = 1;
+  while (running > 0) {
+    if ((rc = mhx_adaptive_advance(e, e->chunk_iters, &running)) != MHX_OK) return rc;
+  }
+  return MHX_OK;
+}
+
+int mhx_adaptive_steps(mhx_engine* e, int64_t n) {
+  mhx_run_opts o;
+  mhx_run_opts_default(&o);
+  o.n = n;               // (walker-adaptive-steps-full walker :n n :temperature 10
+  o.temperature = 10.0;  //                              :auto :prob-settle) M:947
+  o.auto_mode = 1;
+  return mhx_adaptive_steps_full(e, &o);
+}
+
+int mhx_many_steps(mhx_engine* e, int64_t n, const double* L, int per_chain_l) {
+  if (!e || !L) return fail(MHX_EINVAL, "NULL argument (the nil-L default of M:851 is not reproduced)");
+  if (!e->chains_ready) return fail(MHX_ESTATE, "mhx_init_chains has not been called");
+  if (n < 0) return fail(MHX_EINVAL, "n < 0");
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  if ((rc = finalize_problem(e)) != MHX_OK) return rc;
+  const size_t C = (size_t)e->cfg.n_chains, dd = (size_t)e->P.d * e->P.d;
+  if (per_chain_l) {
+    HIP_TRY(hipMemcpy(e->L.p, L, C * dd * sizeof(double), hipMemcpyHostToDevice));
+  } else {
+    std::vector<double> full(C * dd);
+    for (size_t c = 0; c < C; ++c) memcpy(&full[c * dd], L, dd * sizeof(double));
+    HIP_TRY(hipMemcpy(e->L.p, full.data(), full.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  // (dotimes (i n) (walker-take-step w :l-matrix L)) M:852-853: loop index 0..n-1, T = 1
+  RunDesc& R = e->R;
+  R.n = n;
+  R.sts = steps_to_settle_of(e->P.d);
+  R.temp_steps = 0;
+  R.tail = 0;
+  R.auto_mode = 0;
+  R.has_mwl = 0;
+  R.temps = nullptr;
+  R.stop_flag = e->stop_flag.p;
+  HIP_TRY(hipMemset(e->stop_flag.p, 0, sizeof(int32_t)));
+  {
+    std::vector<int64_t> zero(C, 0);
+    std::vector<int32_t> st(C), run(C, MHX_CHAIN_RUNNING);
+    std::vector<double> one(C, 1.0);
+    HIP_TRY(hipMemcpy(st.data(), e->status.p, C * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t c = 0; c < C; ++c)
+      if (st[c] == MHX_CHAIN_FP_TRAP) run[c] = MHX_CHAIN_FP_TRAP;
+    HIP_TRY(hipMemcpy(e->loop_i.p, zero.data(), C * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->status.p, run.data(), C * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->temperature.p, one.data(), C * sizeof(double), hipMemcpyHostToDevice));
+  }
+  int64_t running = 1;
+  while (running > 0) {
+    if ((rc = launch_steps(e, e->chunk_iters, 1)) != MHX_OK) return rc;
+    if ((rc = count_running(e, &running)) != MHX_OK) return rc;
+  }
+  e->run_ready = false;
+  return MHX_OK;
+}
+
+int mhx_request_stop(mhx_engine* e) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  static const int32_t one = 1;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(e->stop_flag.p, &one, sizeof one, hipMemcpyHostToDevice, e->stop_stream));
+  HIP_TRY(hipStreamSynchronize(e->stop_stream));
+  return MHX_OK;
+}
+
+int mhx_set_allreduce(mhx_engine* e, mhx_allreduce_fn fn, void* ctx, int wants_device_buffer) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  e->allreduce = fn;
+  e->allreduce_ctx = ctx;
+  e->allreduce_device = wants_device_buffer;
+  return MHX_OK;
+}
+
+int mhx_get_state(mhx_engine* e, double* theta, double* logpost, double* best_theta,
+                  double* best_logpost, int64_t* length, int64_t* age) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  if (!e->chains_ready) return fail(MHX_ESTATE, "mhx_init_chains has not been called");
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  const size_t C = (size_t)e->cfg.n_chains, d = (size_t)e->P.d;
+  if (theta) HIP_TRY(hipMemcpy(theta, e->theta.p, C * d * sizeof(double), hipMemcpyDeviceToHost));
+  if (logpost) HIP_TRY(hipMemcpy(logpost, e->prob.p, C * sizeof(double), hipMemcpyDeviceToHost));
+  if (best_theta)
+    HIP_TRY(hipMemcpy(best_theta, e->best_theta.p, C * d * sizeof(double), hipMemcpyDeviceToHost));
+  if (best_logpost)
+    HIP_TRY(hipMemcpy(best_logpost, e->best_prob.p, C * sizeof(double), hipMemcpyDeviceToHost));
+  if (length) HIP_TRY(hipMemcpy(length, e->length.p, C * sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (age) HIP_TRY(hipMemcpy(age, e->age.p, C * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return MHX_OK;
+}
+
+int mhx_get_chain_status(mhx_engine* e, int32_t* status, int64_t* loop_index) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  const size_t C = (size_t)e->cfg.n_chains;
+  if (status) HIP_TRY(hipMemcpy(status, e->status.p, C * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (loop_index)
+    HIP_TRY(hipMemcpy(loop_index, e->loop_i.p, C * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return MHX_OK;
+}
+
+int mhx_get_lmatrix(mhx_engine* e, double* L) {
+  if (!e || !L) return fail(MHX_EINVAL, "NULL argument");
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  const size_t C = (size_t)e->cfg.n_chains, dd = (size_t)e->P.d * e->P.d;
+  HIP_TRY(hipMemcpy(L, e->L.p, C * dd * sizeof(double), hipMemcpyDeviceToHost));
+  return MHX_OK;
+}
+
+int mhx_get_temperature(mhx_engine* e, double* T) {
+  if (!e || !T) return fail(MHX_EINVAL, "NULL argument");
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  HIP_TRY(hipMemcpy(T, e->temperature.p, (size_t)e->cfg.n_chains * sizeof(double),
+                    hipMemcpyDeviceToHost));
+  return MHX_OK;
+}
+
+int mhx_get_acceptance(mhx_engine* e, int take, double* out) {
+  if (!e || !out) return fail(MHX_EINVAL, "NULL argument");
+  if (!e->chains_ready) return fail(MHX_ESTATE, "mhx_init_chains has not been called");
+  if (take < 1) return fail(MHX_EINVAL, "take must be >= 1");
+  if (take > e->S.R) return fail(MHX_EINVAL, "take %d exceeds history_capacity %d", take, e->S.R);
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  DevBuf<double> d;
+  const size_t C = (size_t)e->cfg.n_chains;
+  if (d.alloc(C, false) != hipSuccess) return fail(MHX_ENOMEM, "hipMalloc failed");
+  HIP_TRY(launch_acceptance(e->stream, e->S, take, d.p));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(out, d.p, C * sizeof(double), hipMemcpyDeviceToHost));
+  return MHX_OK;
+}
+
+int mhx_get_trace(mhx_engine* e, int64_t chain, int take, double* prob, double* theta,
+                  int* n_out) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  if (!e->chains_ready) return fail(MHX_ESTATE, "mhx_init_chains has not been called");
+  if (chain < 0 || chain >= e->cfg.n_chains) return fail(MHX_EINVAL, "chain out of range");
+  if (take < 0) return fail(MHX_EINVAL, "take < 0");
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  const int Rcap = e->S.R, d = e->P.d;
+  int64_t nh = 0, len = 0;
+  HIP_TRY(hipMemcpy(&nh, e->n_hist.p + chain, sizeof nh, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&len, e->length.p + chain, sizeof len, hipMemcpyDeviceToHost));
+  int64_t avail = std::min<int64_t>(std::min<int64_t>(len, nh), Rcap);
+  int t = (int)std::min<int64_t>(avail, take);
+  if (n_out) *n_out = t;
+  if (t == 0) return MHX_OK;
+  std::vector<double> hp((size_t)Rcap), ht;
+  HIP_TRY(hipMemcpy(hp.data(), e->hist_prob.p + chain * Rcap, (size_t)Rcap * sizeof(double),
+                    hipMemcpyDeviceToHost));
+  if (theta) {
+    ht.resize((size_t)Rcap * d);
+    HIP_TRY(hipMemcpy(ht.data(), e->hist_theta.p + chain * Rcap * d,
+                      (size_t)Rcap * d * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  for (int s = 0; s < t; ++s) {
+    const int slot = (int)((nh - 1 - s) & (Rcap - 1));
+    if (prob) prob[s] = hp[(size_t)slot];
+    if (theta) memcpy(theta + (size_t)s * d, &ht[(size_t)slot * d], sizeof(double) * d);
+  }
+  return MHX_OK;
+}
+
+int mhx_get_proposal_factor(mhx_engine* e, int64_t chain, int take, double* L_out, int* status,
+                            int* n_forward) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  if (!e->chains_ready) return fail(MHX_ESTATE, "mhx_init_chains has not been called");
+  if (chain < 0 || chain >= e->cfg.n_chains) return fail(MHX_EINVAL, "chain out of range");
+  if (take < 1 || take > e->S.R)
+    return fail(MHX_EINVAL, "take must be in [1, history_capacity = %d]", e->S.R);
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  const size_t dd = (size_t)e->P.d * e->P.d;
+  DevBuf<int32_t> fwd, info;
+  DevBuf<double> cov, out;
+  if (fwd.alloc((size_t)take) != hipSuccess || info.alloc(2) != hipSuccess ||
+      cov.alloc(dd) != hipSuccess || out.alloc(dd) != hipSuccess)
+    return fail(MHX_ENOMEM, "hipMalloc failed");
+  HIP_TRY(launch_l_matrix(e->stream, e->S, chain, take, fwd.p, cov.p, out.p, info.p));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  int32_t hinfo[2];
+  HIP_TRY(hipMemcpy(hinfo, info.p, sizeof hinfo, hipMemcpyDeviceToHost));
+  if (status) *status = hinfo[0];
+  if (n_forward) *n_forward = hinfo[1];
+  if (L_out) HIP_TRY(hipMemcpy(L_out, out.p, dd * sizeof(double), hipMemcpyDeviceToHost));
+  return MHX_OK;
+}
+
+int mhx_get_counters(mhx_engine* e, uint64_t* chain_steps, uint64_t* kernel_launches) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  if (chain_steps) {
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpy(&v, e->step_counter.p, sizeof v, hipMemcpyDeviceToHost));
+    *chain_steps = v;
+  }
+  if (kernel_launches) *kernel_launches = e->launches;
+  return MHX_OK;
+}
+
+int mhx_kernel_timing(mhx_engine* e, int reset, double* avg_ms, uint64_t* launches,
+                      double* total_ms) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  if (avg_ms) *avg_ms = e->timed_launches ? e->kernel_ms / (double)e->timed_launches : 0.0;
+  if (launches) *launches = e->timed_launches;
+  if (total_ms) *total_ms = e->kernel_ms;
+  if (reset) {
+    e->kernel_ms = 0.0;
+    e->timed_launches = 0;
+  }
+  return MHX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+// mhx_launch.hpp -- host-callable launchers of the gfx950 kernels (defined in mhx_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mhx_types.hpp"
+
+namespace mhx {
+
+// Compiled problem specialisations.  SPEC_GENERIC dispatches on (model, shape, likelihood) at
+// run time; the others fix one model + likelihood for all K functions so that their
+// parameters live in scalar registers and the kernel's register budget is its own.
+enum SpecId {
+  SPEC_GENERIC = 0,
+  SPEC_GAUSS22_NORMAL = 1,   // 2 background terms + 2 Gaussian peaks, weighted normal (8 params)
+  SPEC_GAUSS15_POISSON = 2,  // constant background + 5 Gaussian peaks, Poisson (16 params)
+  SPEC_PVOIGT2_NORMAL = 3,   // 11-parameter two-peak pseudo-Voigt (global fits)
+  SPEC_POLY2_NORMAL = 4,     // b + m x
+  SPEC_POLY8_NORMAL = 5,     // degree-7 polynomial
+  SPEC_LORDER_NORMAL = 6,    // test.lisp's 6-parameter lineshape
+  SPEC_GAUSS22_CUTOFF = 7,
+  SPEC__COUNT = 8
+};
+
+int select_spec(const ProblemDesc& P);
+const char* spec_name(int spec);
+
+hipError_t configure_kernels();
+size_t group_lds_bytes();
+
+hipError_t launch_logpost(int spec, hipStream_t st, const ProblemDesc* P, const double* theta,
+                          int64_t n, double* out, double* parts);
+hipError_t launch_init(int spec, hipStream_t st, const ProblemDesc* P, const ChainState& S);
+hipError_t launch_step_injected(int spec, hipStream_t st, const ProblemDesc* P,
+                                const ChainState& S, const double* L, int per_chain_l,
+                                const double* z, const double* u, const double* T,
+                                unsigned char* accepted);
+hipError_t launch_adaptive(int spec, hipStream_t st, const ProblemDesc* P, const ChainState& S,
+                           const RunDesc& R, int64_t max_iters, int plain);
+hipError_t launch_initial_l(hipStream_t st, const ChainState& S, const RunDesc& R, int have_l,
+                            double T0);
+hipError_t launch_l_matrix(hipStream_t st, const ChainState& S, int64_t chain, int take, int* fwd,
+                           double* cov, double* out, int* info);
+hipError_t launch_acceptance(hipStream_t st, const ChainState& S, int take, double* out);
+
+}  // namespace mhx

@@ -1,0 +1,84 @@
+// mhx_types.hpp -- structures shared by the host engine and the gfx950 kernels.
+//
+// Data layout in HBM (all IEEE binary64 unless noted):
+//   dataset k      x[n_pad] y[n_pad] w[n_pad] (c[n_pad] for the cutoff likelihood), each a
+//                  separate 256-B aligned array padded to a whole number of tiles; w = 1/sigma;
+//                  pads are (x_last, 0, 0) so a padded point adds exactly +0 to the sum.
+//   chain state    theta[C][d], prob[C], best_theta[C][d], best_prob[C], length/age/draw[C]
+//   history ring   hist_prob[C][R], hist_theta[C][R][d]; n_hist[C] = entries ever pushed,
+//                  entry e lives in slot e % R; the walk of the reference (M:471, newest first)
+//                  is entries n_hist-1, n_hist-2, ...
+//   controller     L[C][d][d] row-major, temperature[C], loop_i[C], flags
+#pragma once
+#include <stdint.h>
+
+#include "../../include/mhx.h"
+
+namespace mhx {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerGroup = 8;           // one wave = one chain; a workgroup shares LDS tiles
+constexpr int kThreads = kWave * kWavesPerGroup;
+constexpr int kTilePoints = 1024;           // data points per LDS tile (per array)
+constexpr int kMaxArrays = 4;               // x, y, w, c
+
+struct FnDesc {
+  int32_t model, lik, n_idx, n_bounds;
+  int32_t shape[4];
+  int32_t idx[MHX_MAX_FN_PARAMS];
+  int32_t bidx[MHX_MAX_BOUNDS];
+  double blo[MHX_MAX_BOUNDS];
+  double bhi[MHX_MAX_BOUNDS];
+  const double* x;
+  const double* y;
+  const double* w;  // 1/sigma (normal), unused (poisson)
+  const double* c;  // -1/2 log(2 pi) - log sigma_i (cutoff only)
+  int64_t n;        // points
+  int64_t n_tiles;  // ceil(n / kTilePoints)
+  double lik_const; // normal: sum_i(-1/2 log 2pi - log sigma_i); poisson: -sum_i logfact(k_i)
+};
+
+struct ProblemDesc {
+  int32_t d, K;
+  FnDesc fn[MHX_MAX_FUNCTIONS];
+};
+
+// per-chain state, structure of arrays
+struct ChainState {
+  int64_t n_chains;
+  int64_t chain_offset;  // global id of local chain 0
+  int32_t d, R;          // R = history ring capacity
+  uint64_t seed;
+  double* theta;
+  double* prob;
+  double* best_theta;
+  double* best_prob;
+  int64_t* length;  // (walker-length w)
+  int64_t* age;     // (walker-age w)
+  uint64_t* draw;   // proposals drawn so far: Philox counter
+  int64_t* n_hist;
+  double* hist_prob;
+  double* hist_theta;
+  // controller
+  double* L;
+  double* temperature;
+  int64_t* loop_i;
+  int64_t* reset_index;
+  int32_t* shutting;
+  int32_t* status;
+  // scratch for the adaptation tick
+  int32_t* fwd_idx;  // [C][sts]
+  double* mat_tmp;   // [C][2][d][d]
+  // pooled-mode statistics [C][1 + d + d*d]
+  double* pool_stats;
+  unsigned long long* step_counter;  // chain-steps taken by all chains (device atomic)
+};
+
+struct RunDesc {
+  int64_t n, sts, temp_steps, mwl, tail;
+  int32_t auto_mode, has_mwl, adapt_mode;
+  const double* temps;  // [temp_steps]
+  const int32_t* stop_flag;
+};
+
+}  // namespace mhx

@@ -1,0 +1,367 @@
+"""The reference's own fitting API over the MI355X engine.
+
+Host-side mirror of the exported Lisp surface of afranson/Lisp-MCMC for the
+walker-adaptive-steps path (M: = mcmc-fitting.lisp):
+
+    walker-create                M:1132-1163   walker_create
+    mcmc-fit                     M:1165-1175   mcmc_fit
+    walker-adaptive-steps        M:946-947     walker_adaptive_steps
+    walker-adaptive-steps-full   M:862-942     walker_adaptive_steps_full
+    walker-many-steps            M:849-853     walker_many_steps
+    walker-take-step             M:1072-1095   walker_take_step
+    walker-get                   M:487-543     walker_get
+    walker-modify                M:547-580     walker_modify
+    prior-bounds-let             M:346-369     prior_bounds
+    mfit-walker-estop            M:860-861     request_stop
+
+Same names (kebab-case -> snake_case), same argument meaning, same error behaviour where
+the path defines one.  All stepping and every log-posterior is computed by libmhx.so on
+the GPU; this file only lays data out the way clean-data / clean-data-error do
+(M:774-825) and turns device read-backs into the reference's return shapes.
+
+Extension: n_chains > 1 makes a walker SET that steps in one batch (the reference maps a
+list of walkers sequentially, M:1029-1033); `chain=` selects a member on read-back.
+"""
+from fractions import Fraction
+
+import numpy as np
+
+from . import _capi as capi
+from .engine import Engine
+from .models import Model
+
+_LIKS = {
+    None: capi.LIK_NORMAL,
+    "normal": capi.LIK_NORMAL, "log-liklihood-normal": capi.LIK_NORMAL,
+    "normal-weighted": capi.LIK_NORMAL, "log-liklihood-normal-weighted": capi.LIK_NORMAL,
+    "normal-cutoff": capi.LIK_NORMAL_CUTOFF, "log-liklihood-normal-cutoff": capi.LIK_NORMAL_CUTOFF,
+    "poisson": capi.LIK_POISSON, "log-poisson": capi.LIK_POISSON,
+}
+
+
+def _key(k):
+    return str(k).lstrip(":").lower()
+
+
+class WalkerStep:
+    """(defstruct walker-step prob params) M:462-464; params is a {key: value} plist"""
+
+    def __init__(self, prob, params):
+        self.prob = float(prob)
+        self.params = params
+
+    def __repr__(self):
+        return "#S(WALKER-STEP :PROB %r :PARAMS %r)" % (self.prob, self.params)
+
+
+class PriorBounds:
+    """The value of a prior whose body is `bounds-total` of (prior-bounds-let ((key lo hi) ...))"""
+
+    def __init__(self, bounds):
+        self.bounds = [(_key(k), float(lo), float(hi)) for k, (lo, hi) in dict(bounds).items()]
+
+
+def prior_bounds(bounds):
+    """(prior-bounds-let ((:a lo hi) ...) bounds-total) M:346-369 as a log-prior designator.
+    -1d10 (exp(1d-5 * distance) - 1) outside (lo, hi), strict at both ends; a key missing from
+    the plist reads as 0d0 (M:353)."""
+    return PriorBounds(bounds)
+
+
+log_prior_flat = None  # (log-prior-flat params data) => 0d0, M:340-343
+
+
+def _force_list(item):  # M:755-759
+    return list(item) if isinstance(item, (list, tuple)) else [item]
+
+
+def _depth(t):  # get-depth M:761-772
+    if isinstance(t, (int, float, np.floating, np.integer)):
+        return 0
+    if isinstance(t, np.ndarray):
+        return t.ndim
+    return 1 + _depth(t[0])
+
+
+def _clean_data(data, n_fn):  # M:807-825
+    dep = _depth(data)
+    if dep == 1:
+        raise ValueError("clean-data: data is of insufficient depth or improperly structured.")
+    if dep == 2:
+        return _clean_data([data], n_fn)
+    if len(data) == n_fn:
+        return [[np.asarray(col, dtype=np.float64) for col in ds] for ds in data]
+    raise ValueError("clean-data: insufficient number of datasets, %d, for the given number of "
+                     "functions, %d." % (len(data), n_fn))
+
+
+def _clean_data_error(stddev, ys):
+    """clean-data-error M:774-805 for the layouts the path uses: a number broadcasts to every
+    y; a structure equal to the y structure is taken as is; anything else broadcasts its
+    first element."""
+    def first(t):
+        while not isinstance(t, (int, float, np.floating, np.integer)):
+            t = t[0]
+        return float(t)
+    if isinstance(stddev, (int, float, np.floating, np.integer)):
+        return [np.full(y.shape, float(stddev)) for y in ys]
+    sd = _force_list(stddev)
+    if len(sd) == len(ys) and all(
+            not isinstance(s, (int, float, np.floating, np.integer)) and len(s) == len(y)
+            for s, y in zip(sd, ys)):
+        return [np.asarray(s, dtype=np.float64) for s in sd]
+    if len(ys) == 1 and len(sd) == len(ys[0]) and all(
+            isinstance(s, (int, float, np.floating, np.integer)) for s in sd):
+        return [np.asarray(sd, dtype=np.float64)]
+    return [np.full(y.shape, first(stddev)) for y in ys]
+
+
+def _plist(params):
+    """(:b -1 :m 2) / {'b': -1, 'm': 2} -> keys in plist order (plist-keys M:190-193), values"""
+    if isinstance(params, dict):
+        items = list(params.items())
+    else:
+        p = list(params)
+        if len(p) % 2:
+            raise ValueError("params plist must have an even number of elements")
+        items = [(p[i], p[i + 1]) for i in range(0, len(p), 2)]
+    keys, vals = [], []
+    for k, v in items:
+        k = _key(k)
+        if k in keys:
+            continue  # first value wins, like getf (M:195-198)
+        if not isinstance(v, (int, float, np.floating, np.integer)):
+            raise capi.MhxError(capi.EUNSUPPORTED,
+                                ":single-item parameter styles (M:1153-1155) are host-side "
+                                "marshalling; pass one key per number")
+        keys.append(k)
+        vals.append(float(v))
+    return keys, np.asarray(vals, dtype=np.float64)
+
+
+class Walker:
+    """(defstruct walker ...) M:467-479 backed by device state."""
+
+    def __init__(self, engine, function, param_keys, data, data_error, log_liklihood, log_prior):
+        self.engine = engine
+        self.function = function
+        self.param_keys = param_keys
+        self.param_style = ":multiple-kwargs"
+        self.data = data
+        self.data_error = data_error
+        self.log_liklihood = log_liklihood
+        self.log_prior = log_prior
+        self.n_chains = engine.n_chains
+
+    # struct accessors (exported M:480)
+    def _step(self, th, pr):
+        return WalkerStep(pr, dict(zip(self.param_keys, (float(v) for v in th))))
+
+    def last_step(self, chain=0):
+        s = self.engine.state()
+        return self._step(s["theta"][chain], s["logpost"][chain])
+
+    def most_likely_step(self, chain=0):
+        s = self.engine.state()
+        return self._step(s["best_theta"][chain], s["best_logpost"][chain])
+
+    def length(self, chain=0):
+        return int(self.engine.state()["length"][chain])
+
+    def age(self, chain=0):
+        return int(self.engine.state()["age"][chain])
+
+    def walk(self, chain=0, take=None):
+        return walker_get(self, get=":steps", take=take, chain=chain)
+
+    def status(self):
+        return self.engine.chain_status()[0]
+
+    def _raise_on_trap(self):
+        st = self.status()
+        if (st == capi.CHAIN_FP_TRAP).any():
+            bad = np.flatnonzero(st == capi.CHAIN_FP_TRAP)
+            raise FloatingPointError(
+                "walker(s) %s: the reference would have signalled an unhandled floating-point "
+                "trap here (non-finite log-posterior, or 0/0 in cholesky-decomp M:597); the "
+                "walker is left where it stood" % bad[:8].tolist())
+
+
+def walker_create(function=None, data=None, params=None, data_error=None, log_liklihood=None,
+                  log_prior=None, param_bounds=None, n_chains=1, theta0=None, device=0, seed=0,
+                  chain_offset=0, history_capacity=0, adapt_mode=capi.ADAPT_FAITHFUL,
+                  poisson_logfact_double=False):
+    """(walker-create &key function data params data-error log-liklihood log-prior param-bounds)
+    M:1132-1163.  function: a models.Model or a list of them; everything else as the reference:
+    each argument may be one item or a list with one item per function (global fit)."""
+    del param_bounds  # (declare (ignorable param-bounds)) M:1141
+    fns = _force_list(function)
+    if not all(isinstance(f, Model) for f in fns):
+        raise TypeError(":function must be a model designator (lisp_mcmc_amd.models), see "
+                        "INTEGRATION.md: a Lisp/Python closure cannot run on the GPU")
+    K = len(fns)
+    dsets = _clean_data(data, K)
+    ys = [ds[1] for ds in dsets]
+    sig = _clean_data_error(1 if data_error is None else data_error, ys)
+    keys, vals = _plist(params)
+    liks = _force_list(log_liklihood) if isinstance(log_liklihood, (list, tuple)) else [log_liklihood] * K
+    pris = _force_list(log_prior) if isinstance(log_prior, (list, tuple)) else [log_prior] * K
+    if len(liks) != K or len(pris) != K:
+        raise ValueError("one log-liklihood / log-prior per function")
+    eng = Engine(n_chains, len(keys), K, device=device, seed=seed, chain_offset=chain_offset,
+                 adapt_mode=adapt_mode, history_capacity=history_capacity,
+                 poisson_logfact_double=poisson_logfact_double)
+    for k, f in enumerate(fns):
+        missing = [q for q in f.keys if q not in keys]
+        if missing:
+            raise KeyError("function %d reads keys %s that :params does not supply" % (k, missing))
+        eng.set_function(k, f.model_id, f.shape, [keys.index(q) for q in f.keys])
+        lk = liks[k]
+        if isinstance(lk, str):
+            lk = lk.lstrip("#':").lower()
+        if lk not in _LIKS:
+            raise capi.MhxError(capi.EUNSUPPORTED, "unknown :log-liklihood %r" % (liks[k],))
+        eng.set_dataset(k, dsets[k][0], dsets[k][1], sig[k], _LIKS[lk])
+        pr = pris[k]
+        if pr is None:
+            eng.set_bounds(k, [], [], [])
+        elif isinstance(pr, PriorBounds):
+            eng.set_bounds(k, [keys.index(q) if q in keys else -1 for q, _, _ in pr.bounds],
+                           [lo for _, lo, _ in pr.bounds], [hi for _, _, hi in pr.bounds])
+        else:
+            raise capi.MhxError(capi.EUNSUPPORTED,
+                                ":log-prior must be None (log-prior-flat) or prior_bounds(...)")
+    eng.init_chains(vals if theta0 is None else np.asarray(theta0, dtype=np.float64))
+    w = Walker(eng, fns, keys, dsets, sig, liks, pris)
+    w._raise_on_trap()
+    return w
+
+
+def walker_adaptive_steps_full(walker, n=100000, temperature=1e3, auto=":prob-settle",
+                               sampling_optimization=":covariance", max_walker_length=None,
+                               l_matrix=None):
+    """(walker-adaptive-steps-full walker &key n temperature auto sampling-optimization
+    max-walker-length l-matrix) M:862"""
+    if sampling_optimization not in (":covariance", "covariance"):
+        raise capi.MhxError(capi.EUNSUPPORTED, ":best-value is outside the accelerated path")
+    if auto in (":slope-settle", "slope-settle"):
+        raise capi.MhxError(capi.EUNSUPPORTED, ":slope-settle is outside the accelerated path")
+    walker.engine.adaptive_steps_full(int(np.floor(n)), temperature, 1 if auto else 0,
+                                      max_walker_length or 0, l_matrix)
+    walker._raise_on_trap()
+    return None
+
+
+def walker_adaptive_steps(walker, n=30000):
+    """(walker-adaptive-steps walker &optional (n 30000)) M:946-947"""
+    return walker_adaptive_steps_full(walker, n=n, temperature=10, auto=":prob-settle")
+
+
+def mcmc_fit(**kw):
+    """(mcmc-fit &key ...) = walker-create + walker-adaptive-steps M:1165-1175"""
+    w = walker_create(**kw)
+    walker_adaptive_steps(w)
+    return w
+
+
+def walker_many_steps(walker, n, l_matrix=None):
+    """(walker-many-steps the-walker n &optional l-matrix) M:849-853"""
+    if l_matrix is None:  # M:851 diag(1e-2 (single float!) * median-params)
+        med = walker_get(walker, get=":median-params")
+        l_matrix = np.diag([float(np.float32(1e-2)) * v for v in med.values()])
+    walker.engine.many_steps(n, l_matrix)
+    walker._raise_on_trap()
+
+
+def walker_take_step(walker, l_matrix=None, temperature=1, z=None, u=None, rng=None):
+    """(walker-take-step walker &key l-matrix (temperature 1)) M:1072-1095.  z / u are the
+    numbers alexandria:gaussian-random (M:687) and (random 1.0d0) (M:1092) would return;
+    when omitted they come from a host generator (the reference's stream is unseeded)."""
+    e = walker.engine
+    if l_matrix is None:  # M:1074
+        ml = walker_get(walker, get=":most-likely-params", take=1000)
+        l_matrix = np.diag([float(np.float32(1e-2)) * v for v in ml.values()])
+    rng = rng or np.random.default_rng()
+    if z is None:
+        z = rng.standard_normal((e.n_chains, e.d))
+    if u is None:
+        u = 1.0 - rng.random(e.n_chains)
+    acc = e.step_injected(l_matrix, z, u, temperature)
+    walker._raise_on_trap()
+    return acc
+
+
+def request_stop(walker):
+    """(setf mfit-walker-estop t) M:860-861"""
+    walker.engine.request_stop()
+
+
+def _percentile(n, seq):  # nth-percentile M:1493-1504
+    copy = np.sort(np.asarray(seq, dtype=np.float64))
+    pos = Fraction(n).limit_denominator(1000) * (len(copy) - 1) / 100
+    lo = pos.numerator // pos.denominator
+    if pos == lo:
+        return float(copy[lo])
+    return float((copy[lo] + copy[lo + 1]) / 2)
+
+
+def walker_get(walker, get=":steps", take=None, param=None, chain=0):
+    """(walker-get walker &key get take param) M:487-543, served from the device trace."""
+    e = walker.engine
+    g = _key(get)
+    keys = walker.param_keys
+    cap = int(e.state()["length"][chain])
+    t = cap if take is None else min(int(take), cap)
+    if g == "most-likely-params":  # M:511-515 (struct slot, not windowed)
+        return dict(walker.most_likely_step(chain).params)
+    if g == "acceptance":  # M:506-508
+        a = e.acceptance(max(t, 1))[chain]
+        return Fraction(int(round(a * t)), t)
+    if g == "l-matrix":  # M:543
+        st, L, _ = e.proposal_factor(chain, max(t, 1))
+        if st == capi.L_CAUGHT:
+            raise ArithmeticError("(walker-get :l-matrix): type-error / division-by-zero / "
+                                  "floating-point-overflow (the conditions M:891-894 handles)")
+        if st == capi.L_INVALID:
+            raise FloatingPointError("(walker-get :l-matrix): floating-point-invalid-operation")
+        return L if st == capi.L_OK else np.zeros((0, 0))
+    prob, th = e.trace(chain, t)
+    steps = [walker._step(th[i], prob[i]) for i in range(len(prob))]
+    if g == "steps":
+        return steps
+    if g == "log-liklihoods":  # M:540
+        return [s.prob for s in steps]
+    if g == "params":
+        return [s.params for s in steps]
+    if g == "param":
+        return [s.params[_key(param)] for s in steps]
+    if g == "unique-steps":  # M:492-496 (equal on probs)
+        return [steps[i].params for i in range(len(steps))
+                if i + 1 >= len(steps) or steps[i].prob != steps[i + 1].prob]
+    if g == "forward-steps":  # M:497-502
+        return [steps[i].params for i in range(len(steps) - 1)
+                if not steps[i].prob <= steps[i + 1].prob]
+    if g == "most-likely-step":  # M:503-505 over the window; ties keep the later element
+        best = steps[0]
+        for s in steps[1:]:
+            best = best if best.prob > s.prob else s
+        return best
+    if g == "median-params":  # M:516-523
+        return {k: _percentile(50, th[:, j]) for j, k in enumerate(keys)}
+    if g == "covariance-matrix":  # M:541 population covariance of the unique steps
+        u = np.array([[p[k] for k in keys] for p in walker_get(walker, ":unique-steps", take, chain=chain)])
+        return np.cov(u.T, bias=True).reshape(len(keys), len(keys))
+    if g == "stddev-params":  # M:525-539 diagonal of the l-matrix
+        if cap < 10:
+            return {k: 0.0 for k in keys}
+        L = walker_get(walker, ":l-matrix", take, chain=chain)
+        return {k: float(L[j, j]) for j, k in enumerate(keys)}
+    raise ValueError("unknown :get %r" % (get,))
+
+
+def walker_modify(walker, modify=None, **kw):
+    """(walker-modify ...) M:547-580: only :add-step is on the accelerated path and it is
+    performed by the device inside walker-take-step; the list-surgery actions are host-side
+    post-processing the engine does not take over yet."""
+    raise capi.MhxError(capi.EUNSUPPORTED,
+                        "walker-modify %s is not part of the accelerated path" % (modify,))

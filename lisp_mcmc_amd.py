@@ -1,0 +1,12 @@
+"""Import alias: `import lisp_mcmc_amd` loads the package in ./lisp-mcmc_amd/ (a hyphen cannot
+appear in an import statement)."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lisp-mcmc_amd")
+_spec = importlib.util.spec_from_file_location(
+    "lisp_mcmc_amd", os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["lisp_mcmc_amd"] = _mod
+_spec.loader.exec_module(_mod)

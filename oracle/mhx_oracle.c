@@ -107,9 +107,10 @@ double orc_model_eval(int model, const int32_t* shape, const double* p, int np, 
  * invalid operation.  The handler-case of M:891-894 catches overflow / div-by-zero /
  * type-error, NOT invalid. */
 static int trap_of(double r) {
-  if (isnan(r)) return ORC_L_INVALID;
-  if (isinf(r)) return ORC_L_CAUGHT;
-  return ORC_L_OK;
+  /* with finite inputs an inf is an overflow and a NaN can only follow an earlier overflow
+   * (inf - inf): either way floating-point-overflow is signalled first and is caught.  The
+   * only invalid operation on this path is the explicit 0/0 of M:597. */
+  return isfinite(r) ? ORC_L_OK : ORC_L_CAUGHT;
 }
 
 /* M:614-643 population covariance; avg via (reduce #'+ x) then / n; the /n sits inside

@@ -1,0 +1,52 @@
+"""CPU-only checks of the drop-in boundary: libmhx.so loads (without a GPU) and exports every
+entry point include/mhx.h declares; the ctypes table covers the header; compute calls fail
+loudly without a device (there is no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "mhx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mhx_[a-z0-9_]+)\s*\(", src)) - {"mhx_allreduce_fn"})
+
+
+def test_library_exports_every_header_symbol():
+    import lisp_mcmc_amd
+    capi = lisp_mcmc_amd.capi
+    lib = capi.lib()
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), n
+        assert n in capi.SIGNATURES, "ctypes table misses %s" % n
+    assert sorted(capi.SIGNATURES) == names
+    assert lib.mhx_version() == 100
+
+
+def test_no_cpu_fallback_without_device():
+    import lisp_mcmc_amd
+    capi = lisp_mcmc_amd.capi
+    n = C.c_int(-1)
+    rc = capi.lib().mhx_device_count(C.byref(n))
+    if rc == capi.OK and n.value > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(lisp_mcmc_amd.MhxError) as ei:
+        lisp_mcmc_amd.Engine(4, 2)
+    assert ei.value.code == capi.EDEVICE
+    assert "no CPU path" in str(ei.value)
+
+
+def test_product_never_touches_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/"""
+    pkg = os.path.join(ROOT, "lisp-mcmc_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".inc", ".h", ".lisp", ".asd")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "oraclelib" not in txt and "mhx_oracle" not in txt and "orc_" not in txt, f
