@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- chain-steps/sec of the walker-adaptive-steps path on MI355X.
+
+One "step" = one iteration of the reference's do loop (mcmc-fitting.lisp:902-942) for EVERY
+chain of the batch: propose, evaluate the full log-posterior over all data points, accept /
+reject, history push, controller bookkeeping (incl. the 200-step proposal adaptation when it
+falls inside the timed region).  Inputs are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|poly7|c1]
+
+N > 1: launched by torch.distributed.run, one rank per GPU; chains are sharded by contiguous
+global id ranges (weak scaling: --chains per GPU), no data-path collective in the reference's
+per-walker adaptation mode.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synth_workload(name, rng_key=0x5EED0001):
+    """Synthetic inputs of BASELINE.json's configs."""
+    import problems as pb
+    rng = np.random.Generator(np.random.Philox(key=rng_key))
+    if name in ("c2", "poly7"):
+        n = 100000
+        x = np.linspace(0.0, 1.0, n)
+        sig = rng.uniform(0.05, 0.15, n)
+        if name == "c2":
+            th = np.array([0.5, 0.3, 1.0, 0.3, 0.05, 0.7, 0.7, 0.08])
+            y = pb.model_eval_np(pb.GAUSS, (2, 2), th, x) + sig * rng.standard_normal(n)
+            s = pb.Spec(8)
+            lo, hi = np.minimum(th * 0.5, th * 1.5), np.maximum(th * 0.5, th * 1.5)
+            s.add(pb.GAUSS, (2, 2), range(8), x, y, sig, pb.NORMAL, (list(range(8)), lo, hi))
+            desc = "4096 chains x 8-param two-Gaussian-peak + linear bg, weighted normal log-lik, 1e5 points, fp64"
+        else:
+            th = np.array([0.5, 0.3, -0.2, 0.1, 0.05, -0.03, 0.02, 0.01])
+            y = pb.model_eval_np(pb.POLY, (), th, x) + sig * rng.standard_normal(n)
+            s = pb.Spec(8)
+            s.add(pb.POLY, (), range(8), x, y, sig, pb.NORMAL,
+                  (list(range(8)), th - 1.0, th + 1.0))
+            desc = "4096 chains x degree-7 polynomial (cheapest 8-param model), weighted normal, 1e5 points"
+        s.theta_star = th
+        return s, 4096, 24, desc
+    if name == "c3":
+        n, npk = 1000000, 5
+        th = [20.0]
+        for k in range(npk):
+            th += [float(rng.uniform(40, 150)), (k + 0.5) / npk, float(rng.uniform(0.02, 0.05))]
+        th = np.array(th)
+        x = np.linspace(0.0, 1.0, n)
+        y = rng.poisson(pb.model_eval_np(pb.GAUSS, (1, npk), th, x)).astype(float)
+        s = pb.Spec(16)
+        s.add(pb.GAUSS, (1, npk), range(16), x, y, None, pb.POISSON,
+              (list(range(16)), th * 0.5, th * 1.5))
+        s.theta_star = th
+        return s, 65536, 16, "65536 chains x 16-param 5-peak Poisson log-lik, 1e6 points"
+    if name == "c4":
+        s = pb.global_fit(n_each=12500, n_sets=8, seed=3)
+        return s, 4096, 24, "4096 chains, 8 datasets x 8 fns sharing 32 params, 12500 points each"
+    if name == "c1":
+        s = pb.lorder()
+        return s, 1, 24, "test.lisp shape: 1 chain, 334 points, 6 params"
+    raise SystemExit("unknown workload %r" % name)
+
+
+def b_alg(spec, b_pt):
+    """algorithmic bytes per chain-step, SURVEY 8d / BASELINE.md section 3"""
+    d = spec.d
+    return sum(len(x) for (x, _, _, _) in spec.data) * b_pt + 8 * d * d + 16 * d + 16
+
+
+def cpu_baseline(spec, theta0, budget_s, n_adapt):
+    """the oracle (CPU restatement of the reference, faithful serial sums, libm) on ONE host
+    core, same workload, bounded sample"""
+    import oraclelib as orc
+    op = spec.oracle(orc)
+    w = orc.Walker(op, theta0)
+    w.adaptive_begin(n_adapt, 10.0, 1, seed=0x5EED0003, chain_id=0)
+    steps, t0 = 0, time.perf_counter()
+    chunk = 1
+    while True:
+        w.adaptive_advance(chunk)
+        steps += chunk
+        el = time.perf_counter() - t0
+        if el >= budget_s or w.status != orc.RUNNING:
+            break
+        chunk = max(1, min(64, int(chunk * 2)))
+    return steps / el, steps, el
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import lisp_mcmc_amd as mhx
+
+    spec, chains, b_pt, desc = synth_workload(args.workload)
+    if args.chains:
+        chains = args.chains
+    n_adapt = 30000  # (walker-adaptive-steps w) default n, mcmc-fitting.lisp:946
+    e = spec.engine(mhx, chains, device=local_rank if world > 1 else 0, seed=0x5EED0003,
+                    chain_offset=rank * chains)
+    # per-chain start: theta* (1 + 0.01 N(0,1)), keyed by GLOBAL chain id
+    rng = np.random.Generator(np.random.Philox(key=0x5EED0002 + rank))
+    th0 = spec.theta_star[None, :] * (1.0 + 0.01 * rng.standard_normal((chains, spec.d)))
+    e.init_chains(th0)
+    e.adaptive_begin(n_adapt, 10.0, 1)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        e.adaptive_advance(args.warmup, count=False)
+    e.kernel_timing(reset=True)
+    steps0 = e.counters()[0]
+    sync()
+    t0 = time.perf_counter()
+    e.adaptive_advance(args.steps, count=False)  # one launch, K loop iterations per chain
+    sync()
+    t1 = time.perf_counter()
+    el = t1 - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    kt = e.kernel_timing()
+    chain_steps = e.counters()[0] - steps0
+    if dist is not None:
+        t = torch.tensor([float(chain_steps)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total_steps = float(t.item())
+    else:
+        total_steps = float(chain_steps)
+    st, _ = e.chain_status()
+    assert (st != mhx.capi.CHAIN_FP_TRAP).all(), "a chain trapped during the benchmark"
+    assert chain_steps == chains * args.steps, (chain_steps, chains, args.steps)
+
+    bytes_step = b_alg(spec, b_pt)
+    kernel_s = kt["total_ms"] * 1e-3
+    achieved = chain_steps * bytes_step / kernel_s / 1e9  # this rank's dominant kernel
+    out = {
+        "metric": "chain-steps/sec (whole node), 1e5-pt Gaussian log-lik, 8 params"
+                  if args.workload == "c2" else "chain-steps/sec (whole node), workload %s" % args.workload,
+        "value": total_steps / el,
+        "unit": "chain-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": el / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": desc, "chains_per_gpu": chains, "n_points": int(sum(len(d[0]) for d in spec.data)),
+                   "n_params": spec.d, "adaptation": "faithful per-walker (no collective)",
+                   "parallelism": "chains sharded over %d GPU(s)" % world,
+                   "kernel": "k_adaptive<%s>" % args.workload},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_chain_step": bytes_step,
+                     "kernel_ms_per_launch": kt["avg_ms"], "launches": kt["launches"],
+                     "note": "dataset is L2/MALL resident and shared by the chains of a workgroup "
+                             "through LDS; the kernel is fp64-VALU bound (DESIGN.md)"},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        v, n_s, t_s = cpu_baseline(spec, th0[0], args.cpu_seconds, n_adapt)
+        out["cpu_baseline"] = {"value": v, "unit": "chain-steps/s", "cores": 1, "kind": "port",
+                               "sample": "1 chain x %d steps of the same workload (%.1f s), "
+                                         "oracle/ faithful serial order, glibc libm" % (n_s, t_s)}
+    if rank == 0:
+        print(json.dumps(out))
+    e.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

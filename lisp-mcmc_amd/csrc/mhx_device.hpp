@@ -154,7 +154,36 @@ __device__ __forceinline__ double rng_lane_value(uint64_t seed, uint64_t gchain,
 // device models (formula spec: include/mhx.h).  Prep holds wave-uniform values (SGPRs).
 // PF = functor int -> double giving local parameter j of the function (uniform).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double mexp(double s) { return exp(s); }
+// 2^s for s <= 0 (also fine for moderate s > 0).  s = k + f, k = rint(s) by the 1.5*2^52
+// trick, f in [-1/2, 1/2] EXACT (no hi/lo reduction constants: the callers fold log2(e)
+// into their own scale factors, so the argument already IS a base-2 exponent);
+// 2^f by a degree-11 near-minimax polynomial (tools/gen_exp2_coeffs.py: 2.0e-17 relative
+// after rounding the coefficients), scaled by v_ldexp_f64.  v_cvt_i32_f64 saturates, so
+// s -> -inf side underflows to 0 through ldexp; NaN propagates (a NaN log-posterior is where
+// the reference would have trapped).  16 VALU instructions, < 1 ulp.
+__device__ __forceinline__ double mexp2(double s) {
+  const double MAGIC = 0x1.8p52;
+  const double kd = s + MAGIC;
+  const double kf = kd - MAGIC;
+  const double f = s - kf;
+  double p = 0x1.e9d3fe3952179p-32;
+  p = __builtin_fma(p, f, 0x1.e6063f7217bc6p-28);
+  p = __builtin_fma(p, f, 0x1.b524fae627834p-24);
+  p = __builtin_fma(p, f, 0x1.62bfd47773353p-20);
+  p = __builtin_fma(p, f, 0x1.ffcbfc670dcd4p-17);
+  p = __builtin_fma(p, f, 0x1.430913096fd9fp-13);
+  p = __builtin_fma(p, f, 0x1.5d87fe78a5276p-10);
+  p = __builtin_fma(p, f, 0x1.3b2ab6fba1ddap-7);
+  p = __builtin_fma(p, f, 0x1.c6b08d704a0c2p-5);
+  p = __builtin_fma(p, f, 0x1.ebfbdff82c598p-3);
+  p = __builtin_fma(p, f, 0x1.62e42fefa39efp-1);
+  p = __builtin_fma(p, f, 1.0);
+  return ldexp(p, (int)kf);
+}
+constexpr double kLog2e = 1.4426950408889634074;       // log2(e)
+constexpr double kSqrtLog2e = 1.2011224087864497594;   // sqrt(log2(e))
+// exp(s) through mexp2 (relative error ~ 2 ulp * |s|: callers use it on decaying terms)
+__device__ __forceinline__ double mexp(double s) { return mexp2(s * kLog2e); }
 
 template <int NBG, int NPK, bool LORENTZ>
 struct PeaksModel {
@@ -170,8 +199,11 @@ struct PeaksModel {
 #pragma unroll
     for (int k = 0; k < NPK; ++k) {
       p.A[k] = uniform_f64(pf(NBG + 3 * k));
-      p.mu[k] = uniform_f64(pf(NBG + 3 * k + 1));
-      p.iw[k] = uniform_f64(1.0 / pf(NBG + 3 * k + 2));
+      const double mu = pf(NBG + 3 * k + 1);
+      // Gaussian: exp(-((x-mu)/w)^2) = 2^(-t^2) with t = x*iw' - mu*iw', iw' = sqrt(log2 e)/w
+      const double iw = LORENTZ ? 1.0 / pf(NBG + 3 * k + 2) : kSqrtLog2e / pf(NBG + 3 * k + 2);
+      p.iw[k] = uniform_f64(iw);
+      p.mu[k] = uniform_f64(-mu * iw);  // additive constant of the fma below
     }
     return p;
   }
@@ -184,12 +216,11 @@ struct PeaksModel {
     }
 #pragma unroll
     for (int k = 0; k < NPK; ++k) {
-      double t = (x - p.mu[k]) * p.iw[k];
-      double s = t * t;
+      const double t = __builtin_fma(x, p.iw[k], p.mu[k]);
       if (LORENTZ)
-        f = f + p.A[k] / (1.0 + s);
+        f = f + p.A[k] / __builtin_fma(t, t, 1.0);
       else
-        f = __builtin_fma(p.A[k], mexp(-s), f);
+        f = __builtin_fma(p.A[k], mexp2(-(t * t)), f);
     }
     return f;
   }
@@ -210,9 +241,12 @@ struct PeaksModelDyn {
     int l = lane_id();
     int np = p.nbg + 3 * p.npk;
     if (l < np) {
+      // same folding as PeaksModel: slot mu holds -mu*iw, slot w holds iw (Gaussian: *sqrt(log2 e))
+      const int r = l >= p.nbg ? (l - p.nbg) % 3 : -1;
       double v = pf(l);
-      bool is_w = l >= p.nbg && ((l - p.nbg) % 3) == 2;
-      scratch[l] = is_w ? 1.0 / v : v;
+      if (r == 2) v = (LORENTZ ? 1.0 : kSqrtLog2e) / v;
+      if (r == 1) v = -v * ((LORENTZ ? 1.0 : kSqrtLog2e) / pf(l + 1));
+      scratch[l] = v;
     }
     p.q = scratch;
     return p;
@@ -225,12 +259,11 @@ struct PeaksModelDyn {
     }
     for (int k = 0; k < p.npk; ++k) {
       const double* q = p.q + p.nbg + 3 * k;
-      double t = (x - q[1]) * q[2];
-      double s = t * t;
+      const double t = __builtin_fma(x, q[2], q[1]);
       if (LORENTZ)
-        f = f + q[0] / (1.0 + s);
+        f = f + q[0] / __builtin_fma(t, t, 1.0);
       else
-        f = __builtin_fma(q[0], mexp(-s), f);
+        f = __builtin_fma(q[0], mexp2(-(t * t)), f);
     }
     return f;
   }

@@ -418,6 +418,7 @@ int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y, cons
       if (!(s > 0.0) || !std::isfinite(s))
         return fail(MHX_EINVAL, "sigma[%zu] = %g must be finite and > 0 (M:376)", i, s);
       hw[i] = 1.0 / s;
+      hy[i] = y[i] * hw[i];  // the kernel forms r = y/sigma - m/sigma with one fma
       hc[i] = half_log_2pi + (-1.0 * std::log(s));  // first two terms of M:377
       csum += (long double)hc[i];
     }

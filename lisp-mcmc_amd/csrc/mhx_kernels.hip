@@ -26,19 +26,28 @@ struct GroupLds {
 // ------------------------------------------------------------------------------------------
 // LDS tile pipeline + per-lane accumulation of one function's likelihood sum
 // ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+// Tile t of every array of function f -> LDS buffer `buf`, by LDS-DMA (global_load_lds_dwordx4:
+// no VGPR staging; each wave instruction lands 64 x 16 B = 1 KiB contiguously at a
+// wave-uniform LDS base).  Asynchronous: retired by the s_waitcnt vmcnt(0) the compiler puts in
+// front of the next __syncthreads().
 template <int NARR>
-__device__ __forceinline__ void tile_fetch(const FnDesc& f, int64_t t, double2 regs[NARR]) {
+__device__ __forceinline__ void tile_dma(const FnDesc& f, int64_t t, GroupLds& lds, int buf,
+                                         int w) {
   const int64_t base = t * kTilePoints + 2 * (int)threadIdx.x;
-  regs[0] = *reinterpret_cast<const double2*>(f.x + base);
-  regs[1] = *reinterpret_cast<const double2*>(f.y + base);
-  if constexpr (NARR > 2) regs[2] = *reinterpret_cast<const double2*>(f.w + base);
-  if constexpr (NARR > 3) regs[3] = *reinterpret_cast<const double2*>(f.c + base);
-}
-template <int NARR>
-__device__ __forceinline__ void tile_store(GroupLds& lds, int buf, const double2 regs[NARR]) {
-#pragma unroll
-  for (int a = 0; a < NARR; ++a)
-    *reinterpret_cast<double2*>(&lds.tiles[buf][a][2 * (int)threadIdx.x]) = regs[a];
+  const int wbase = 2 * kWave * w;  // first element this wave fills
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)(f.x + base), (lds_ptr_t)&lds.tiles[buf][0][wbase],
+                                   16, 0, 0);
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)(f.y + base), (lds_ptr_t)&lds.tiles[buf][1][wbase],
+                                   16, 0, 0);
+  if constexpr (NARR > 2)
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(f.w + base),
+                                     (lds_ptr_t)&lds.tiles[buf][2][wbase], 16, 0, 0);
+  if constexpr (NARR > 3)
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(f.c + base),
+                                     (lds_ptr_t)&lds.tiles[buf][3][wbase], 16, 0, 0);
 }
 
 // Sum over the points of function f.  Collective over the workgroup (barriers inside);
@@ -49,16 +58,16 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
   constexpr int NARR = LIK == MHX_LIK_POISSON ? 2 : (LIK == MHX_LIK_NORMAL_CUTOFF ? 4 : 3);
   static_assert(kTilePoints == 2 * kThreads, "one double2 per thread per array per tile");
   const int l = lane_id();
+  const int w = wave_in_group();
   const int64_t nt = f.n_tiles;
   double acc0 = 0.0, acc1 = 0.0;
   if (nt == 0) return 0.0;
-  double2 regs[NARR];
-  tile_fetch<NARR>(f, 0, regs);
-  tile_store<NARR>(lds, 0, regs);
+  tile_dma<NARR>(f, 0, lds, 0, w);
   __syncthreads();
   for (int64_t t = 0; t < nt; ++t) {
     const int buf = (int)(t & 1);
-    if (t + 1 < nt) tile_fetch<NARR>(f, t + 1, regs);
+    // buffer buf^1 was last read in iteration t-1, which every wave left through the barrier
+    if (t + 1 < nt) tile_dma<NARR>(f, t + 1, lds, buf ^ 1, w);
     if (active) {
       const double* tx = lds.tiles[buf][0];
       const double* ty = lds.tiles[buf][1];
@@ -73,11 +82,12 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
         const double m0 = Model::eval(prep, x0);
         const double m1 = Model::eval(prep, x1);
         if (LIK == MHX_LIK_NORMAL) {
-          const double r0 = (y0 - m0) * tw[i0], r1 = (y1 - m1) * tw[i1];
+          // the y array holds y/sigma (host, once): r = y/sigma - m/sigma in one fma
+          const double r0 = __builtin_fma(-m0, tw[i0], y0), r1 = __builtin_fma(-m1, tw[i1], y1);
           acc0 = __builtin_fma(r0, r0, acc0);
           acc1 = __builtin_fma(r1, r1, acc1);
         } else if (LIK == MHX_LIK_NORMAL_CUTOFF) {
-          const double r0 = (y0 - m0) * tw[i0], r1 = (y1 - m1) * tw[i1];
+          const double r0 = __builtin_fma(-m0, tw[i0], y0), r1 = __builtin_fma(-m1, tw[i1], y1);
           const double t0 = __builtin_fma(-0.5 * r0, r0, tc[i0]);
           const double t1 = __builtin_fma(-0.5 * r1, r1, tc[i1]);
           acc0 = acc0 + (t0 > -5000.0 ? t0 : -5000.0);  // (max -5000d0 term) M:426
@@ -92,8 +102,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
         }
       }
     }
-    if (t + 1 < nt) tile_store<NARR>(lds, buf ^ 1, regs);
-    __syncthreads();
+    __syncthreads();  // also drains this wave's DMA (vmcnt(0)) before anyone reads buf^1
   }
   return wave_sum(acc0 + acc1);
 }

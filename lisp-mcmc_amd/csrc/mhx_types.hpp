@@ -1,7 +1,7 @@
 // mhx_types.hpp -- structures shared by the host engine and the gfx950 kernels.
 //
 // Data layout in HBM (all IEEE binary64 unless noted):
-//   dataset k      x[n_pad] y[n_pad] w[n_pad] (c[n_pad] for the cutoff likelihood), each a
+//   dataset k      x[n_pad] y[n_pad] (= y/sigma for the normal likelihoods) w[n_pad] (c[n_pad] for the cutoff likelihood), each a
 //                  separate 256-B aligned array padded to a whole number of tiles; w = 1/sigma;
 //                  pads are (x_last, 0, 0) so a padded point adds exactly +0 to the sum.
 //   chain state    theta[C][d], prob[C], best_theta[C][d], best_prob[C], length/age/draw[C]
