@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--adapt", default="auto", choices=["auto", "faithful", "pooled"],
+                    help="auto: the reference's per-walker rule on 1 GPU, pooled covariance "
+                         "(one RCCL all-reduce per 200 iterations) on several")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -128,8 +131,15 @@ def main():
     if args.chains:
         chains = args.chains
     n_adapt = 30000  # (walker-adaptive-steps w) default n, mcmc-fitting.lisp:946
+    pooled = args.adapt == "pooled" or (args.adapt == "auto" and world > 1)
     e = spec.engine(mhx, chains, device=local_rank if world > 1 else 0, seed=0x5EED0003,
-                    chain_offset=rank * chains)
+                    chain_offset=rank * chains,
+                    adapt_mode=mhx.capi.ADAPT_POOLED if pooled else mhx.capi.ADAPT_FAITHFUL)
+    if pooled and dist is not None:
+        # the one exchange step of the path: 1+d+d^2 doubles summed over ranks every 200
+        # iterations, RCCL over xGMI directly on the engine's device buffer
+        from lisp_mcmc_amd import distributed as mdist
+        e.set_allreduce(mdist.torch_allreduce_hook(dist), device_buffer=True)
     # per-chain start: theta* (1 + 0.01 N(0,1)), keyed by GLOBAL chain id
     rng = np.random.Generator(np.random.Philox(key=0x5EED0002 + rank))
     th0 = spec.theta_star[None, :] * (1.0 + 0.01 * rng.standard_normal((chains, spec.d)))
@@ -186,7 +196,9 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": desc, "chains_per_gpu": chains, "n_points": int(sum(len(d[0]) for d in spec.data)),
-                   "n_params": spec.d, "adaptation": "faithful per-walker (no collective)",
+                   "n_params": spec.d,
+                   "adaptation": ("pooled covariance, all-reduce of %d doubles / 200 iterations" % (1 + spec.d + spec.d ** 2))
+                   if pooled else "faithful per-walker (no collective)",
                    "parallelism": "chains sharded over %d GPU(s)" % world,
                    "kernel": "k_adaptive<%s>" % args.workload},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -224,6 +224,12 @@ int mhx_get_trace(mhx_engine* e, int64_t chain, int take, double* prob, double* 
 int mhx_get_proposal_factor(mhx_engine* e, int64_t chain, int take, double* L_out,
                             int* status, int* n_forward);
 
+/* MHX_ADAPT_POOLED read-back: stats [1+d+d*d] = (n, sum delta, sum delta delta^T) pooled over
+ * chains (and ranks) at the last 200-iteration tick; L_pool [d][d] = (2.38^2/d) chol(cov);
+ * valid = 1 when that factor is in use; refreshes = ticks performed. */
+int mhx_get_pooled(mhx_engine* e, double* stats, double* L_pool, int32_t* valid,
+                   uint64_t* refreshes);
+
 /* Total chain-steps taken by this engine since creation (all chains). */
 int mhx_get_counters(mhx_engine* e, uint64_t* chain_steps, uint64_t* kernel_launches);
 

@@ -97,7 +97,10 @@ struct mhx_engine {
 
   ChainState S{};
   DevBuf<double> theta, prob, best_theta, best_prob, hist_prob, hist_theta, L, temperature,
-      mat_tmp, pool_stats;
+      mat_tmp, pool_stats, pool_vec, L_pool;
+  DevBuf<int32_t> pool_valid;
+  int64_t global_iter = 0;  // loop iterations launched since mhx_adaptive_begin (pooled cadence)
+  uint64_t pool_refreshes = 0;
   DevBuf<int64_t> length, age, n_hist, loop_i, reset_index;
   DevBuf<uint64_t> draw;
   DevBuf<int32_t> shutting, status, fwd_idx, stop_flag;
@@ -216,6 +219,9 @@ int alloc_state(mhx_engine* e) {
   ALLOC(pool_stats, C * (1 + d + d * d));
   ALLOC(stop_flag, 1);
   ALLOC(step_counter, 1);
+  ALLOC(pool_vec, 1 + d + d * d);
+  ALLOC(L_pool, d * d);
+  ALLOC(pool_valid, 1);
 #undef ALLOC
   S.theta = e->theta.p;
   S.prob = e->prob.p;
@@ -237,6 +243,9 @@ int alloc_state(mhx_engine* e) {
   S.mat_tmp = e->mat_tmp.p;
   S.pool_stats = e->pool_stats.p;
   S.step_counter = e->step_counter.p;
+  S.pool_vec = e->pool_vec.p;
+  S.L_pool = e->L_pool.p;
+  S.pool_valid = e->pool_valid.p;
   return MHX_OK;
 }
 
@@ -266,6 +275,34 @@ int launch_steps(mhx_engine* e, int64_t iters, int plain) {
     int64_t want = (int64_t)(50.0 / std::max(per_iter, 1e-6));
     e->chunk_iters = std::min<int64_t>(std::max<int64_t>(want, 8), 1 << 16);
   }
+  return MHX_OK;
+}
+
+// Pooled adaptation tick (MHX_ADAPT_POOLED): per-chain displacement statistics -> sum over the
+// chains of this rank (fixed order) -> all-reduce over ranks (caller's hook: RCCL through
+// torch.distributed, or any MPI-like sum) -> covariance, Cholesky, 2.38^2/d on every rank.
+int pool_refresh(mhx_engine* e) {
+  const size_t E = 1 + (size_t)e->P.d + (size_t)e->P.d * e->P.d;
+  HIP_TRY(launch_pool_stats(e->stream, e->S, e->R));
+  HIP_TRY(launch_pool_reduce(e->stream, e->S));
+  if (e->allreduce) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    int rc;
+    if (e->allreduce_device) {
+      rc = e->allreduce(e->allreduce_ctx, e->pool_vec.p, E, 1);
+    } else {
+      std::vector<double> h(E);
+      HIP_TRY(hipMemcpy(h.data(), e->pool_vec.p, E * sizeof(double), hipMemcpyDeviceToHost));
+      rc = e->allreduce(e->allreduce_ctx, h.data(), E, 0);
+      if (rc == 0)
+        HIP_TRY(hipMemcpy(e->pool_vec.p, h.data(), E * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (rc != 0) return fail(MHX_ECOMM, "all-reduce hook returned %d", rc);
+  }
+  HIP_TRY(launch_pool_factor(e->stream, e->S));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->launches += 3;
+  e->pool_refreshes++;
   return MHX_OK;
 }
 
@@ -598,6 +635,8 @@ int mhx_adaptive_begin(mhx_engine* e, const mhx_run_opts* o) {
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->launches++;
   e->run_ready = true;
+  e->global_iter = 0;
+  HIP_TRY(hipMemset(e->pool_valid.p, 0, sizeof(int32_t)));
   return MHX_OK;
 }
 
@@ -607,7 +646,22 @@ int mhx_adaptive_advance(mhx_engine* e, int64_t max_iters, int64_t* n_running) {
   if (max_iters < 0) return fail(MHX_EINVAL, "max_iters < 0");
   int rc = use_device(e);
   if (rc != MHX_OK) return rc;
-  if (max_iters > 0 && (rc = launch_steps(e, max_iters, 0)) != MHX_OK) return rc;
+  if (e->cfg.adapt_mode == MHX_ADAPT_POOLED) {
+    // launches end on the pooled cadence (every 200 iterations since begin), where the
+    // displacement statistics of all chains and ranks are combined
+    int64_t left = max_iters;
+    while (left > 0) {
+      const int64_t to_tick = 200 - (e->global_iter % 200);
+      const int64_t now = std::min(left, to_tick);
+      if ((rc = launch_steps(e, now, 0)) != MHX_OK) return rc;
+      e->global_iter += now;
+      left -= now;
+      if (e->global_iter % 200 == 0 && (rc = pool_refresh(e)) != MHX_OK) return rc;
+    }
+  } else if (max_iters > 0) {
+    if ((rc = launch_steps(e, max_iters, 0)) != MHX_OK) return rc;
+    e->global_iter += max_iters;
+  }
   if (n_running) return count_running(e, n_running);
   return MHX_OK;
 }
@@ -811,6 +865,19 @@ int mhx_get_proposal_factor(mhx_engine* e, int64_t chain, int take, double* L_ou
   if (status) *status = hinfo[0];
   if (n_forward) *n_forward = hinfo[1];
   if (L_out) HIP_TRY(hipMemcpy(L_out, out.p, dd * sizeof(double), hipMemcpyDeviceToHost));
+  return MHX_OK;
+}
+
+int mhx_get_pooled(mhx_engine* e, double* stats, double* L_pool, int32_t* valid,
+                   uint64_t* refreshes) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  const size_t d = (size_t)e->P.d, E = 1 + d + d * d;
+  if (stats) HIP_TRY(hipMemcpy(stats, e->pool_vec.p, E * sizeof(double), hipMemcpyDeviceToHost));
+  if (L_pool) HIP_TRY(hipMemcpy(L_pool, e->L_pool.p, d * d * sizeof(double), hipMemcpyDeviceToHost));
+  if (valid) HIP_TRY(hipMemcpy(valid, e->pool_valid.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (refreshes) *refreshes = e->pool_refreshes;
   return MHX_OK;
 }
 

@@ -27,6 +27,7 @@ struct GroupLds {
 // LDS tile pipeline + per-lane accumulation of one function's likelihood sum
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(3))) double* lds_dptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 // Tile t of every array of function f -> LDS buffer `buf`, by LDS-DMA (global_load_lds_dwordx4:
@@ -294,10 +295,10 @@ __device__ __forceinline__ int trap_of(double r) { return finite_f64(r) ? L_OK :
 // (walker-get :get :l-matrix :take take) M:543 = Cholesky of the population covariance of the
 // displacements between successive forward steps.  fwd: int scratch [>= take]; cov, Lout:
 // double scratch [d*d]; avg: LDS scratch [d].  Returns L_* (uniform).
-__device__ __noinline__ int ring_l_matrix(const Ring& r, int take, int* fwd, double* cov,
-                                          double* Lout, double* avg, int* n_forward) {
-  const int t = r.window(take), l = lane_id(), d = r.d;
-  // forward steps M:497-502, newest first, compacted in order
+// forward steps M:497-502 of the newest `take` steps, newest first, compacted in order into
+// fwd[] (ring slots); returns their number (uniform)
+__device__ __forceinline__ int ring_forward_list(const Ring& r, int take, int* fwd) {
+  const int t = r.window(take), l = lane_id();
   int nf = 0;
   for (int base = 0; base < t - 1; base += kWave) {
     const int s = base + l;
@@ -311,6 +312,41 @@ __device__ __noinline__ int ring_l_matrix(const Ring& r, int take, int* fwd, dou
     if (f) fwd[pos] = r.slot(s);
     nf += __popcll(m);
   }
+  return nf;
+}
+
+// cholesky-decomp M:583-598 by ONE lane in the reference's loop order (diagonal
+// sqrt(max 0 .), upper triangle 0).  Returns L_OK / L_CAUGHT (x/0, overflow) / L_INVALID (0/0).
+__device__ __forceinline__ int cholesky_seq(const double* cov, double* Lout, int d) {
+  int cst = L_OK;
+  for (int e = 0; e < d * d; ++e) Lout[e] = 0.0;
+  for (int i = 0; i < d && cst == L_OK; ++i)
+    for (int k = 0; k <= i && cst == L_OK; ++k) {
+      double tmp = 0.0;
+      for (int j = 0; j < k; ++j) tmp = tmp + Lout[i * d + j] * Lout[k * d + j];
+      cst = trap_of(tmp);
+      if (cst != L_OK) break;
+      if (i == k) {
+        const double a = cov[i * d + k] - tmp;
+        Lout[i * d + k] = ieee_sqrt(a > 0.0 ? a : 0.0);  // (sqrt (max 0d0 a)) M:596
+      } else {
+        const double num = cov[i * d + k] - tmp, den = Lout[k * d + k];
+        if (den == 0.0) {
+          cst = num == 0.0 ? L_INVALID : L_CAUGHT;
+        } else {
+          const double q = num / den;
+          cst = trap_of(q);
+          Lout[i * d + k] = q;
+        }
+      }
+    }
+  return cst;
+}
+
+__device__ __noinline__ int ring_l_matrix(const Ring& r, int take, int* fwd, double* cov,
+                                          double* Lout, lds_dptr_t avg, int* n_forward) {
+  const int l = lane_id(), d = r.d;
+  const int nf = ring_forward_list(r, take, fwd);
   *n_forward = nf;
   if (nf == 0) return L_CAUGHT;  // (elt nil 0): an index error is a type-error
   if (nf == 1) return L_EMPTY;
@@ -363,29 +399,7 @@ __device__ __noinline__ int ring_l_matrix(const Ring& r, int take, int* fwd, dou
   __threadfence();
   // cholesky-decomp M:583-598, one lane, the reference's loop order
   int cst = L_OK;
-  if (l == 0) {
-    for (int e = 0; e < d * d; ++e) Lout[e] = 0.0;
-    for (int i = 0; i < d && cst == L_OK; ++i)
-      for (int k = 0; k <= i && cst == L_OK; ++k) {
-        double tmp = 0.0;
-        for (int j = 0; j < k; ++j) tmp = tmp + Lout[i * d + j] * Lout[k * d + j];
-        cst = trap_of(tmp);
-        if (cst != L_OK) break;
-        if (i == k) {
-          const double a = cov[i * d + k] - tmp;
-          Lout[i * d + k] = ieee_sqrt(a > 0.0 ? a : 0.0);  // (sqrt (max 0d0 a)) M:596
-        } else {
-          const double num = cov[i * d + k] - tmp, den = Lout[k * d + k];
-          if (den == 0.0) {
-            cst = num == 0.0 ? L_INVALID : L_CAUGHT;
-          } else {
-            const double q = num / den;
-            cst = trap_of(q);
-            Lout[i * d + k] = q;
-          }
-        }
-      }
-  }
+  if (l == 0) cst = cholesky_seq(cov, Lout, d);
   cst = __builtin_amdgcn_readfirstlane(cst);
   __threadfence();
   return cst;
@@ -689,7 +703,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_adaptive(const ProblemDesc* __r
         if ((m200 && acc_lt(num, den, 0.2f)) || (m200 && acc_gt(num, den, 0.4f)) || msts) {
           if (acc_gt(num, den, 0.2f) && acc_lt(num, den, 0.4f)) {
             int nf;
-            const int st = ring_l_matrix(ring, (int)R.sts, fwd, covs, lnew, lds.prop[w], &nf);
+            int st;
+            if (R.adapt_mode == MHX_ADAPT_POOLED && *(volatile const int*)S.pool_valid != 0) {
+              // extension: the factor of the covariance pooled over all chains and ranks
+              // (already scaled by 2.38^2/d) replaces the walker's own estimate
+              for (int e = l; e < d * d; e += kWave) Lc[e] = S.L_pool[e];
+              st = L_EMPTY;  // nothing more to do below
+            } else {
+              st = ring_l_matrix(ring, (int)R.sts, fwd, covs, lnew, (lds_dptr_t)lds.prop[w], &nf);
+            }
             if (st == L_OK) {
               for (int e = l; e < d * d; e += kWave) Lc[e] = factor * lnew[e];
             } else if (st == L_CAUGHT) {  // handler-case returns the CURRENT l-matrix, which
@@ -755,7 +777,7 @@ __global__ __launch_bounds__(kThreads) void k_initial_l(ChainState S, RunDesc R,
     double* lnew = covs + d * d;
     const double factor = (2.38 * 2.38) / (double)d;
     int nf;
-    const int st = ring_l_matrix(ring, (int)R.sts, fwd, covs, lnew, lds.prop[w], &nf);
+    const int st = ring_l_matrix(ring, (int)R.sts, fwd, covs, lnew, (lds_dptr_t)lds.prop[w], &nf);
     if (st == L_OK) {
       for (int e = l; e < d * d; e += kWave) Lc[e] = factor * lnew[e];
     } else if (st == L_CAUGHT) {
@@ -786,11 +808,87 @@ __global__ __launch_bounds__(kWave) void k_l_matrix(ChainState S, int64_t c, int
   ring.nh = uniform_i64(S.n_hist[c]);
   ring.length = uniform_i64(S.length[c]);
   int nf = 0;
-  const int st = ring_l_matrix(ring, take, fwd, cov, out, avg, &nf);
+  const int st = ring_l_matrix(ring, take, fwd, cov, out, (lds_dptr_t)avg, &nf);
   if (lane_id() == 0) {
     info[0] = st;
     info[1] = nf;
   }
+}
+
+// ---- pooled adaptive covariance (extension of the north star; not in the reference) --------
+// Step 1: every chain reduces the displacements between its successive forward steps (the
+// vectors lplist-covariance would see, M:543) to (n, sum delta, sum delta delta^T).
+__global__ __launch_bounds__(kThreads) void k_pool_stats(ChainState S, RunDesc R) {
+  const int w = wave_in_group(), l = lane_id(), d = S.d;
+  const int64_t c = (int64_t)blockIdx.x * kWavesPerGroup + w;
+  if (c >= S.n_chains) return;
+  const int E = 1 + d + d * d;
+  double* out = S.pool_stats + c * E;
+  Ring ring;
+  ring.prob = S.hist_prob + c * S.R;
+  ring.theta = S.hist_theta + c * S.R * d;
+  ring.mask = S.R - 1;
+  ring.d = d;
+  ring.nh = uniform_i64(S.n_hist[c]);
+  ring.length = uniform_i64(S.length[c]);
+  int* fwd = S.fwd_idx + c * R.sts;
+  const int nf = S.status[c] == MHX_CHAIN_FP_TRAP ? 0 : ring_forward_list(ring, (int)R.sts, fwd);
+  __threadfence();
+  const int M = nf >= 2 ? nf - 1 : 0;
+  auto diff = [&](int k, int p) -> double {
+    return ring.theta[(int64_t)fwd[k + 1] * d + p] - ring.theta[(int64_t)fwd[k] * d + p];
+  };
+  if (l == 0) out[0] = (double)M;
+  if (l < d) {
+    double s = 0.0;
+    for (int k = 0; k < M; ++k) s = s + diff(k, l);
+    out[1 + l] = s;
+  }
+  for (int e = l; e < d * d; e += kWave) {
+    const int i = e / d, j = e - i * d;
+    double q = 0.0;
+    for (int k = 0; k < M; ++k) q = __builtin_fma(diff(k, i), diff(k, j), q);
+    out[1 + d + e] = q;
+  }
+}
+
+// Step 2: sum over the chains of this rank, one block per entry, fixed order (reproducible)
+__global__ __launch_bounds__(256) void k_pool_reduce(ChainState S) {
+  __shared__ double part[256];
+  const int d = S.d, E = 1 + d + d * d, e = blockIdx.x, t = threadIdx.x;
+  double s = 0.0;
+  for (int64_t c = t; c < S.n_chains; c += 256) s = s + S.pool_stats[c * E + e];
+  part[t] = s;
+  __syncthreads();
+  for (int h = 128; h >= 1; h >>= 1) {
+    if (t < h) part[t] = part[t] + part[t + h];
+    __syncthreads();
+  }
+  if (t == 0) S.pool_vec[e] = part[0];
+}
+
+// Step 3 (after the all-reduce over ranks): covariance, clamped Cholesky, 2.38^2/d scaling
+__global__ __launch_bounds__(kWave) void k_pool_factor(ChainState S) {
+  const int l = lane_id(), d = S.d;
+  const double* v = S.pool_vec;
+  double* cov = S.mat_tmp;  // chain 0's scratch is free between step launches
+  const double n = v[0];
+  int st = L_CAUGHT;
+  if (n >= 2.0) {
+    for (int e = l; e < d * d; e += kWave) {
+      const int i = e / d, j = e - i * d;
+      cov[e] = v[1 + d + e] / n - (v[1 + i] / n) * (v[1 + j] / n);
+    }
+    __threadfence();
+    st = L_OK;
+    if (l == 0) st = cholesky_seq(cov, S.L_pool, d);
+    st = __builtin_amdgcn_readfirstlane(st);
+    __threadfence();
+    const double factor = (2.38 * 2.38) / (double)d;
+    if (st == L_OK)
+      for (int e = l; e < d * d; e += kWave) S.L_pool[e] = factor * S.L_pool[e];
+  }
+  if (l == 0) *S.pool_valid = st == L_OK ? 1 : 0;
 }
 
 __global__ __launch_bounds__(kThreads) void k_acceptance(ChainState S, int take,

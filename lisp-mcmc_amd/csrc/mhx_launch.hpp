@@ -41,5 +41,8 @@ hipError_t launch_initial_l(hipStream_t st, const ChainState& S, const RunDesc& 
 hipError_t launch_l_matrix(hipStream_t st, const ChainState& S, int64_t chain, int take, int* fwd,
                            double* cov, double* out, int* info);
 hipError_t launch_acceptance(hipStream_t st, const ChainState& S, int take, double* out);
+hipError_t launch_pool_stats(hipStream_t st, const ChainState& S, const RunDesc& R);
+hipError_t launch_pool_reduce(hipStream_t st, const ChainState& S);
+hipError_t launch_pool_factor(hipStream_t st, const ChainState& S);
 
 }  // namespace mhx

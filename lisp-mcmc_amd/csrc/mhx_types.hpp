@@ -69,8 +69,13 @@ struct ChainState {
   // scratch for the adaptation tick
   int32_t* fwd_idx;  // [C][sts]
   double* mat_tmp;   // [C][2][d][d]
-  // pooled-mode statistics [C][1 + d + d*d]
+  // pooled-mode statistics [C][1 + d + d*d]: (n, sum delta, sum delta delta^T) of the chain's
+  // forward-step displacements; pool_vec [1 + d + d*d] = their sum over chains (and ranks);
+  // L_pool [d][d] = (2.38^2/d) * chol(pooled covariance); pool_valid = 1 when usable
   double* pool_stats;
+  double* pool_vec;
+  double* L_pool;
+  int32_t* pool_valid;
   unsigned long long* step_counter;  // chain-steps taken by all chains (device atomic)
 };
 

@@ -196,6 +196,15 @@ class Engine:
                                                       C.byref(nf)))
         return st.value, L, nf.value
 
+    def pooled(self):
+        d = self.d
+        stats, L = np.zeros(1 + d + d * d), np.zeros((d, d))
+        valid, n = C.c_int32(0), C.c_uint64(0)
+        capi.check(capi.lib().mhx_get_pooled(self._h, stats.ctypes.data_as(capi.f64p),
+                                             L.ctypes.data_as(capi.f64p), C.byref(valid),
+                                             C.byref(n)))
+        return dict(stats=stats, L=L, valid=bool(valid.value), refreshes=n.value)
+
     def counters(self):
         a, b = C.c_uint64(0), C.c_uint64(0)
         capi.check(capi.lib().mhx_get_counters(self._h, C.byref(a), C.byref(b)))

@@ -370,3 +370,65 @@ def test_walker_api_line_fit(mhx, golden):
     assert abs(med["m"] - bm[1]) < 0.1
     L = m.walker_get(w, get=":l-matrix", take=500)
     assert L.shape == (2, 2) and L[0, 1] == 0.0
+
+
+def host_pooled_stats(e, C, d, take=500):
+    out = np.zeros(1 + d + d * d)
+    for c in range(C):
+        prob, th = e.trace(c, take)
+        fwd = [i for i in range(len(prob) - 1) if prob[i] > prob[i + 1]]
+        if len(fwd) < 2:
+            continue
+        v = np.array([th[fwd[k + 1]] - th[fwd[k]] for k in range(len(fwd) - 1)])
+        out[0] += len(v)
+        out[1:1 + d] += v.sum(0)
+        out[1 + d:] += (v.T @ v).ravel()
+    return out
+
+
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_pooled_adaptation_tick(mhx, ranks):
+    """MHX_ADAPT_POOLED (extension): every 200 iterations the forward-step displacement
+    statistics of all chains are summed (k_pool_stats/k_pool_reduce), all-reduced through the
+    hook, and turned into one shared factor (2.38^2/d) chol(cov)"""
+    s = pb.two_peak(n=400, seed=61)
+    C_, d = 24, s.d
+    e = s.engine(mhx, C_, seed=5, adapt_mode=mhx.capi.ADAPT_POOLED)
+    calls = []
+
+    def hook(buf, n, dev):   # stands for `ranks` identical ranks: sum = ranks * local
+        import ctypes
+        a = np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ctypes.c_double)), shape=(n,))
+        calls.append((n, dev, a.copy()))
+        a *= ranks
+        return 0
+    e.set_allreduce(hook, device_buffer=False)
+    e.init_chains(pb.perturbed(s.theta_star, C_, 0.01))
+    e.adaptive_begin(5000, 10.0, 0, l_matrix=np.diag(0.01 * np.abs(s.theta_star)))
+    assert e.adaptive_advance(150) == C_ and e.pooled()["refreshes"] == 0
+    e.adaptive_advance(50)                      # iteration 200: first tick
+    p = e.pooled()
+    assert p["refreshes"] == 1 and len(calls) == 1 and calls[0][0] == 1 + d + d * d
+    host = host_pooled_stats(e, C_, d)
+    assert np.allclose(calls[0][2], host, rtol=1e-12, atol=1e-300)
+    assert np.allclose(p["stats"], ranks * host, rtol=1e-12, atol=1e-300)
+    n = p["stats"][0]
+    mean = p["stats"][1:1 + d] / n
+    cov = p["stats"][1 + d:].reshape(d, d) / n - np.outer(mean, mean)
+    assert p["valid"]
+    assert np.allclose(p["L"], (2.38 ** 2 / d) * np.linalg.cholesky(cov), rtol=1e-7, atol=1e-12)
+    # a chain re-estimates its factor only at i % (2*steps-to-settle) = 0 with acceptance in
+    # (0.2, 0.4) (M:932-938); in pooled mode it then adopts the factor of the latest tick
+    e.adaptive_advance(600)
+    p800 = e.pooled()
+    assert p800["refreshes"] == 4 and p800["valid"]
+    e.adaptive_advance(200)
+    acc = e.acceptance(200)
+    Ls = e.lmatrix()
+    adopted = [c for c in range(C_) if np.array_equal(Ls[c], p800["L"])]
+    lo, hi = float(np.float32(0.2)), float(np.float32(0.4))   # single-float literals of M:934
+    band = [c for c in range(C_) if lo < acc[c] < hi]
+    assert set(band) == set(adopted)
+    st, _ = e.chain_status()
+    assert (st == mhx.capi.CHAIN_RUNNING).all()
+    e.close()
