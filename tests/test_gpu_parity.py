@@ -372,6 +372,37 @@ def test_walker_api_line_fit(mhx, golden):
     assert L.shape == (2, 2) and L[0, 1] == 0.0
 
 
+def test_pooled_rccl_hook_on_device_buffer(mhx):
+    """the N > 1 exchange step as bench.py wires it: torch.distributed 'nccl' (= RCCL)
+    all-reduce directly on the engine's device buffer (1-rank group on this 1-GPU box)"""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from lisp_mcmc_amd import distributed as mdist
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        s = pb.two_peak(n=300, seed=62)
+        C_, d = 16, s.d
+        e = s.engine(mhx, C_, seed=6, adapt_mode=mhx.capi.ADAPT_POOLED)
+        e.set_allreduce(mdist.torch_allreduce_hook(dist), device_buffer=True)
+        e.init_chains(pb.perturbed(s.theta_star, C_, 0.01))
+        e.adaptive_begin(5000, 10.0, 0, l_matrix=np.diag(0.01 * np.abs(s.theta_star)))
+        e.adaptive_advance(200)
+        p = e.pooled()
+        assert p["refreshes"] == 1 and p["valid"]
+        assert np.allclose(p["stats"], host_pooled_stats(e, C_, d), rtol=1e-12, atol=1e-300)
+        e.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def host_pooled_stats(e, C, d, take=500):
     out = np.zeros(1 + d + d * d)
     for c in range(C):
