@@ -144,7 +144,10 @@ def main():
     rng = np.random.Generator(np.random.Philox(key=0x5EED0002 + rank))
     th0 = spec.theta_star[None, :] * (1.0 + 0.01 * rng.standard_normal((chains, spec.d)))
     e.init_chains(th0)
-    e.adaptive_begin(n_adapt, 10.0, 1)
+    # c3: a Poisson rate must stay positive (log-poisson of a negative rate is an error in the
+    # reference as well), so the run starts from a small :l-matrix instead of diag(theta) (M:899)
+    l0 = np.diag(0.002 * np.abs(spec.theta_star)) if args.workload == "c3" else None
+    e.adaptive_begin(n_adapt, 10.0, 1, l_matrix=l0)
 
     def sync():
         torch.cuda.synchronize()

@@ -84,6 +84,32 @@ class MhxError(RuntimeError):
         self.code = code
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7, the name libmhx.so needs); if this process may also use torch
+    (bench.py: torch.distributed / RCCL), load that copy first so libmhx.so binds to it instead
+    of /opt/rocm's - two live HIP runtimes in one process cannot both see the GPU.  Without
+    torch installed nothing happens and libmhx.so uses the ROCm installation's runtime."""
+    import importlib.util
+    import sys
+    if os.environ.get("MHX_NO_TORCH_HIP"):
+        return
+    if "torch" in sys.modules:
+        return  # already loaded: the loader will reuse it by SONAME
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libmhx.so (built by lisp-mcmc_amd/csrc/Makefile or __graft_entry__.build())."""
     global _lib
@@ -92,6 +118,7 @@ def lib():
             raise ImportError(
                 "%s is missing: build it with `make -C lisp-mcmc_amd/csrc` (hipcc, gfx950). "
                 "There is no CPU fallback." % LIB_PATH)
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header and library disagree

@@ -483,6 +483,11 @@ int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y, cons
   f.n_tiles = (int64_t)nt;
   f.lik = likelihood;
   f.lik_const = (double)csum;
+  f.xmin = f.xmax = n ? x[0] : 0.0;
+  for (size_t i = 1; i < n; ++i) {
+    f.xmin = std::min(f.xmin, x[i]);
+    f.xmax = std::max(f.xmax, x[i]);
+  }
   D.set = true;
   e->problem_dirty = true;
   return MHX_OK;

@@ -53,7 +53,7 @@ __device__ __forceinline__ void tile_dma(const FnDesc& f, int64_t t, GroupLds& l
 
 // Sum over the points of function f.  Collective over the workgroup (barriers inside);
 // waves with active == false only help to move tiles.
-template <class Model, int LIK>
+template <class Model, int LIK, bool FAST = false>
 __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::Prep& prep,
                                         bool active, GroupLds& lds) {
   constexpr int NARR = LIK == MHX_LIK_POISSON ? 2 : (LIK == MHX_LIK_NORMAL_CUTOFF ? 4 : 3);
@@ -75,13 +75,36 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
       const double* tw = lds.tiles[buf][2];
       const double* tc = lds.tiles[buf][3];
       const int64_t gbase = t * kTilePoints;
+      if constexpr (LIK == MHX_LIK_NORMAL) {
+        // software-pipelined: the LDS reads of the next two points are issued before the
+        // ~76 dependent fp64 instructions of the current two, so no wave waits on lgkmcnt
+        double xa = tx[l], xb = tx[l + kWave], ya = ty[l], yb = ty[l + kWave];
+        double wa = tw[l], wb = tw[l + kWave];
+#pragma unroll
+        for (int k = 0; k < kTilePoints / kWave; k += 2) {
+          double xn = 0, xm = 0, yn = 0, ym = 0, wn = 0, wm = 0;
+          if (k + 2 < kTilePoints / kWave) {
+            const int j = (k + 2) * kWave + l;
+            xn = tx[j]; xm = tx[j + kWave];
+            yn = ty[j]; ym = ty[j + kWave];
+            wn = tw[j]; wm = tw[j + kWave];
+          }
+          __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the arithmetic below
+          const double m0 = model_eval<Model, FAST>(prep, xa);
+          const double m1 = model_eval<Model, FAST>(prep, xb);
+          const double r0 = __builtin_fma(-m0, wa, ya), r1 = __builtin_fma(-m1, wb, yb);
+          acc0 = __builtin_fma(r0, r0, acc0);
+          acc1 = __builtin_fma(r1, r1, acc1);
+          xa = xn; xb = xm; ya = yn; yb = ym; wa = wn; wb = wm;
+        }
+      } else
 #pragma unroll 2
       for (int k = 0; k < kTilePoints / kWave; k += 2) {
         const int i0 = k * kWave + l, i1 = i0 + kWave;
         const double x0 = tx[i0], x1 = tx[i1];
         const double y0 = ty[i0], y1 = ty[i1];
-        const double m0 = Model::eval(prep, x0);
-        const double m1 = Model::eval(prep, x1);
+        const double m0 = model_eval<Model, FAST>(prep, x0);
+        const double m1 = model_eval<Model, FAST>(prep, x1);
         if (LIK == MHX_LIK_NORMAL) {
           // the y array holds y/sigma (host, once): r = y/sigma - m/sigma in one fma
           const double r0 = __builtin_fma(-m0, tw[i0], y0), r1 = __builtin_fma(-m1, tw[i1], y1);
@@ -122,7 +145,13 @@ struct FixedSpec {
   static __device__ __forceinline__ double loglik(const FnDesc& f, PF pf, bool active,
                                                   GroupLds& lds, double*) {
     typename Model::Prep prep = Model::prepare(pf, f);
-    return finish_lik<LIK>(f, sweep<Model, LIK>(f, prep, active, lds));
+    if constexpr (model_has_fast<Model>::value) {
+      // uniform over the WORKGROUP only if every wave takes the same branch: the barriers
+      // inside sweep() are workgroup-wide, so the choice is voted
+      const bool fast = __syncthreads_and(!active || Model::fast_ok(prep)) != 0;
+      if (fast) return finish_lik<LIK>(f, sweep<Model, LIK, true>(f, prep, active, lds));
+    }
+    return finish_lik<LIK>(f, sweep<Model, LIK, false>(f, prep, active, lds));
   }
 };
 

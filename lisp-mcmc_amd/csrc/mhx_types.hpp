@@ -36,6 +36,7 @@ struct FnDesc {
   int64_t n;        // points
   int64_t n_tiles;  // ceil(n / kTilePoints)
   double lik_const; // normal: sum_i(-1/2 log 2pi - log sigma_i); poisson: -sum_i logfact(k_i)
+  double xmin, xmax; // range of x over the n points (fast-path preconditions of the models)
 };
 
 struct ProblemDesc {
