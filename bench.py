@@ -211,6 +211,19 @@ def main():
                      "note": "dataset is L2/MALL resident and shared by the chains of a workgroup "
                              "through LDS; the kernel is fp64-VALU bound (DESIGN.md)"},
     }
+    # HBM traffic of this launch from the PMC passes committed under profiles/ (rocprofv3 cannot
+    # run inside this process): FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024,
+    # measured on the same command (200 iterations x 4096 chains), scaled by chain-steps
+    prof = os.path.join(ROOT, "profiles", "r01_%s_summary.json" % args.workload)
+    if os.path.exists(prof) and world == 1:
+        try:
+            ps = json.load(open(prof))
+            prof_steps = ps["bench_stats"]["steps"] * ps["bench_stats"]["config"]["chains_per_gpu"]
+            per_step = (ps["hbm_read_bytes"] + ps["hbm_write_bytes"]) / prof_steps
+            out["roofline"]["traffic"] = per_step * chain_steps
+            out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(prof)
+        except Exception:  # a malformed summary must not break the benchmark
+            pass
     if rank == 0 and world == 1 and not args.no_cpu:
         v, n_s, t_s = cpu_baseline(spec, th0[0], args.cpu_seconds, n_adapt)
         out["cpu_baseline"] = {"value": v, "unit": "chain-steps/s", "cores": 1, "kind": "port",
