@@ -307,6 +307,62 @@ def test_adaptive_given_l_and_max_walker_length(mhx, orc):
     e.close()
 
 
+def test_adaptive_second_call_uses_window_covariance(mhx, orc):
+    """a walker that already has >= steps-to-settle steps and acceptance(100) >= 0.1 starts the
+    next walker-adaptive-steps from get-optimal-mcmc-l-matrix, not diag(theta) (M:896-901)"""
+    s = pb.two_peak(n=300, seed=45)
+    C_ = 5
+    e = s.engine(mhx, C_, seed=21)
+    op = s.oracle(orc)
+    th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=21)
+    e.init_chains(th0)
+    ws = [orc.Walker(op, th0[c]) for c in range(C_)]
+    L0 = np.diag(0.004 * np.abs(s.theta_star))
+    for rnd in range(2):
+        e.adaptive_begin(2600, 10.0, 1, 0, L0 if rnd == 0 else None)
+        for c, w in enumerate(ws):
+            w.adaptive_begin(2600, 10.0, 1, 0, L0 if rnd == 0 else None, seed=21, chain_id=c)
+        Ls = e.lmatrix()
+        for c, w in enumerate(ws):
+            assert np.array_equal(Ls[c], w.current_l()), (rnd, c)
+        if rnd == 1:  # the second start is a scaled Cholesky factor: lower triangular, not diagonal
+            assert any(np.count_nonzero(np.tril(Ls[c], -1)) > 0 for c in range(C_))
+        e.adaptive_advance(1 << 40)
+        st = e.state()
+        for c, w in enumerate(ws):
+            w.adaptive_advance(1 << 40)
+            assert np.array_equal(st["theta"][c], w.last()[0]), (rnd, c)
+            assert st["age"][c] == w.age
+    e.close()
+
+
+def test_cholesky_invalid_operation_freezes_the_walker(mhx, orc):
+    """a parameter that never moves gives a zero pivot and 0/0 in cholesky-decomp (M:597):
+    floating-point-invalid-operation is NOT among the conditions M:891-894 handles, so the
+    reference run would end in the debugger; the chain is frozen with MHX_CHAIN_FP_TRAP"""
+    s = pb.two_peak(n=200, seed=46, bounds=False)
+    C_ = 6
+    L0 = np.diag(0.004 * np.abs(s.theta_star))
+    L0[0, 0] = 0.0                                   # theta_0 is never proposed away
+    e = s.engine(mhx, C_, seed=31)
+    op = s.oracle(orc)
+    th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=31)
+    e.init_chains(th0)
+    ws = [orc.Walker(op, th0[c]) for c in range(C_)]
+    e.adaptive_begin(20000, 1.0, 0, 0, L0)
+    for c, w in enumerate(ws):
+        w.adaptive_begin(20000, 1.0, 0, 0, L0, seed=31, chain_id=c)
+    e.adaptive_advance(3000)
+    status, loop_i = e.chain_status()
+    st = e.state()
+    for c, w in enumerate(ws):
+        w.adaptive_advance(3000)
+        assert status[c] == w.status and loop_i[c] == w.loop_index, c
+        assert np.array_equal(st["theta"][c], w.last()[0])
+    assert (status == mhx.capi.CHAIN_FP_TRAP).any(), "the scenario should trap at least once"
+    e.close()
+
+
 def test_estop(mhx):
     s = pb.two_peak(n=200, seed=3)
     e = s.engine(mhx, 4, seed=1)
