@@ -31,8 +31,16 @@
 #ifndef MHX_H
 #define MHX_H
 
+#ifndef __HIPCC_RTC__
 #include <stddef.h>
 #include <stdint.h>
+#else /* hiprtc (run-time compiled expression kernels): no libc headers, built-in types */
+using __hip_internal::int32_t;
+using __hip_internal::int64_t;
+using __hip_internal::uint32_t;
+using __hip_internal::uint64_t;
+using __hip_internal::uint8_t;
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -85,7 +93,8 @@ enum {
   MHX_MODEL_EXP_DECAY = 4,
   MHX_MODEL_SINUSOID = 5,
   MHX_MODEL_PVOIGT2 = 6,
-  MHX_MODEL__COUNT = 7
+  MHX_MODEL_EXPR = 7, /* set by mhx_set_function_expr, never passed to mhx_set_function */
+  MHX_MODEL__COUNT = 8
 };
 
 /* ---- likelihood kinds (what the reference's :log-liklihood closure computes) */
@@ -170,6 +179,20 @@ int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y,
  * the plist" (getf default 0d0, M:353).  n == 0 -> log-prior-flat (M:340-343). */
 int mhx_set_bounds(mhx_engine* e, int k, const int32_t* idx, const double* lo,
                    const double* hi, int n);
+/* Function k given as an EXPRESSION: what a host shim makes of the body
+ * of (lambda (x &key a b &allow-other-keys) <body>) (M:1134-1137).  `expr` is a C-syntax
+ * arithmetic expression over `x`, the identifiers in param_names (local parameter j =
+ * theta[param_index[j]]), numeric literals, + - * / ?: < <= > >= == != && || !, and the
+ * functions exp log sqrt sin cos tan atan tanh abs pow min max.  It is compiled for gfx950
+ * with hiprtc into the same fused kernels when the problem is finalised (first
+ * mhx_init_chains / mhx_logpost), and evaluated without contraction. */
+int mhx_set_function_expr(mhx_engine* e, int k, const char* expr, const char* const* param_names,
+                          const int32_t* param_index, int n_index);
+/* Body of function k's prior-bounds-let prior (M:366-369) as an expression over
+ * `bounds_total` (the sum of the block set by mhx_set_bounds) and the identifiers in `names`
+ * (names[i] = theta[index[i]]), e.g. NV's "bounds_total + (mu1 > mu2 ? -1e9 : 0.0)". */
+int mhx_set_prior_expr(mhx_engine* e, int k, const char* expr, const char* const* names,
+                       const int32_t* index, int n);
 /* First step of every chain (M:1148-1150): theta0 is [n_chains][d], or [d] when
  * broadcast != 0.  Resets history, age, length, most-likely step. */
 int mhx_init_chains(mhx_engine* e, const double* theta0, int broadcast);

@@ -13,6 +13,8 @@ from . import _capi as capi  # noqa: F401
 from ._capi import MhxError  # noqa: F401
 from .engine import Engine  # noqa: F401
 from . import models  # noqa: F401
+from . import sexpr  # noqa: F401
+from . import distributed  # noqa: F401
 from .walker import (  # noqa: F401
     Walker, WalkerStep, walker_create, mcmc_fit, walker_adaptive_steps,
     walker_adaptive_steps_full, walker_many_steps, walker_take_step, walker_get,

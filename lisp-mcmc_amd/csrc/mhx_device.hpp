@@ -9,7 +9,9 @@
 //
 // M: = mcmc-fitting.lisp of the reference.
 #pragma once
+#ifndef __HIPCC_RTC__  // hiprtc pre-includes the runtime header
 #include <hip/hip_runtime.h>
+#endif
 
 #include "mhx_types.hpp"
 

@@ -15,7 +15,10 @@
 #include <vector>
 
 #include "../../include/mhx.h"
+#include <memory>
+
 #include "mhx_launch.hpp"
+#include "mhx_rtc.hpp"
 #include "mhx_types.hpp"
 
 using namespace mhx;
@@ -93,6 +96,10 @@ struct mhx_engine {
   Dataset data[MHX_MAX_FUNCTIONS];
   DevBuf<ProblemDesc> dP;
   bool problem_dirty = true;
+  UserExpr fn_expr[MHX_MAX_FUNCTIONS];     // MHX_MODEL_EXPR bodies
+  UserExpr prior_expr[MHX_MAX_FUNCTIONS];  // prior-bounds-let bodies
+  std::unique_ptr<UserProgram> user_prog;
+  std::string user_key;
   int spec = SPEC_GENERIC;
 
   ChainState S{};
@@ -135,12 +142,63 @@ int finalize_problem(mhx_engine* e) {
     if (!e->fn_set[k]) return fail(MHX_ESTATE, "function %d was never set (mhx_set_function)", k);
     if (!e->data[k].set) return fail(MHX_ESTATE, "dataset %d was never set (mhx_set_dataset)", k);
   }
+  // expression models / prior bodies: assign slots, compile once per distinct problem text
+  std::vector<UserExpr> models, priors;
+  for (int k = 0; k < e->P.K; ++k) {
+    FnDesc& f = e->P.fn[k];
+    f.user_slot = f.prior_slot = -1;
+    if (f.model == MHX_MODEL_EXPR) {
+      f.user_slot = (int)models.size();
+      models.push_back(e->fn_expr[k]);
+    }
+    if (!e->prior_expr[k].expr.empty()) {
+      f.prior_slot = (int)priors.size();
+      priors.push_back(e->prior_expr[k]);
+    }
+  }
   HIP_TRY(hipMemcpy(e->dP.p, &e->P, sizeof(ProblemDesc), hipMemcpyHostToDevice));
-  e->spec = select_spec(e->P);
-  if (const char* s = getenv("MHX_FORCE_GENERIC"))
-    if (atoi(s) != 0) e->spec = SPEC_GENERIC;
+  if (!models.empty() || !priors.empty()) {
+    std::string key;
+    for (auto& u : models) key += "M:" + u.expr + "|";
+    for (auto& u : priors) key += "P:" + u.expr + "|";
+    if (!e->user_prog || key != e->user_key) {
+      std::unique_ptr<UserProgram> prog(new UserProgram());
+      std::string err;
+      if (rtc_build(models, priors, e->P.d, prog.get(), &err) != 0)
+        return fail(MHX_EUNSUPPORTED, "%s", err.c_str());
+      e->user_prog = std::move(prog);
+      e->user_key = key;
+    }
+    e->spec = SPEC_USER;
+  } else {
+    e->spec = select_spec(e->P);
+    if (const char* s = getenv("MHX_FORCE_GENERIC"))
+      if (atoi(s) != 0) e->spec = SPEC_GENERIC;
+  }
   e->problem_dirty = false;
   return MHX_OK;
+}
+
+// launch through the ahead-of-time table or the run-time compiled module
+hipError_t do_logpost(mhx_engine* e, const double* th, int64_t n, double* out, double* parts) {
+  return e->spec == SPEC_USER
+             ? rtc_launch_logpost(*e->user_prog, e->stream, e->dP.p, th, n, out, parts)
+             : launch_logpost(e->spec, e->stream, e->dP.p, th, n, out, parts);
+}
+hipError_t do_init(mhx_engine* e) {
+  return e->spec == SPEC_USER ? rtc_launch_init(*e->user_prog, e->stream, e->dP.p, e->S)
+                              : launch_init(e->spec, e->stream, e->dP.p, e->S);
+}
+hipError_t do_step_injected(mhx_engine* e, const double* L, int pcl, const double* z,
+                            const double* u, const double* T, unsigned char* acc) {
+  return e->spec == SPEC_USER
+             ? rtc_launch_step_injected(*e->user_prog, e->stream, e->dP.p, e->S, L, pcl, z, u, T, acc)
+             : launch_step_injected(e->spec, e->stream, e->dP.p, e->S, L, pcl, z, u, T, acc);
+}
+hipError_t do_adaptive(mhx_engine* e, int64_t iters, int plain) {
+  return e->spec == SPEC_USER
+             ? rtc_launch_adaptive(*e->user_prog, e->stream, e->dP.p, e->S, e->R, iters, plain)
+             : launch_adaptive(e->spec, e->stream, e->dP.p, e->S, e->R, iters, plain);
 }
 
 int check_model(int model, const int32_t* shape, int n_shape, int n_index) {
@@ -261,7 +319,7 @@ int count_running(mhx_engine* e, int64_t* n_running) {
 // one timed launch of the fused step kernel
 int launch_steps(mhx_engine* e, int64_t iters, int plain) {
   HIP_TRY(hipEventRecord(e->ev0, e->stream));
-  HIP_TRY(launch_adaptive(e->spec, e->stream, e->dP.p, e->S, e->R, iters, plain));
+  HIP_TRY(do_adaptive(e, iters, plain));
   HIP_TRY(hipEventRecord(e->ev1, e->stream));
   HIP_TRY(hipEventSynchronize(e->ev1));
   float ms = 0.f;
@@ -418,6 +476,7 @@ int mhx_set_function(mhx_engine* e, int k, int model_id, const int32_t* shape, i
     f.idx[j] = param_index[j];
   }
   f.model = model_id;
+  e->fn_expr[k] = UserExpr();
   f.n_idx = n_index;
   for (int i = 0; i < 4; ++i) f.shape[i] = i < n_shape ? shape[i] : 0;
   e->fn_set[k] = true;
@@ -511,6 +570,69 @@ int mhx_set_bounds(mhx_engine* e, int k, const int32_t* idx, const double* lo, c
   return MHX_OK;
 }
 
+static bool valid_ident(const char* s) {
+  if (!s || !(isalpha((unsigned char)s[0]) || s[0] == '_')) return false;
+  for (const char* p = s; *p; ++p)
+    if (!(isalnum((unsigned char)*p) || *p == '_')) return false;
+  return strcmp(s, "x") != 0 && strcmp(s, "bounds_total") != 0;
+}
+
+int mhx_set_function_expr(mhx_engine* e, int k, const char* expr, const char* const* param_names,
+                          const int32_t* param_index, int n_index) {
+  if (!e || !expr) return fail(MHX_EINVAL, "engine/expr is NULL");
+  if (k < 0 || k >= e->P.K) return fail(MHX_EINVAL, "function index %d out of range", k);
+  if (n_index < 0 || n_index > MHX_MAX_FN_PARAMS || (n_index > 0 && (!param_names || !param_index)))
+    return fail(MHX_EINVAL, "n_index must be in [0,%d]", MHX_MAX_FN_PARAMS);
+  UserExpr u;
+  for (int j = 0; j < n_index; ++j) {
+    if (!valid_ident(param_names[j]))
+      return fail(MHX_EINVAL, "parameter name %d is not an identifier (or is x / bounds_total)", j);
+    if (param_index[j] < 0 || param_index[j] >= e->P.d)
+      return fail(MHX_EINVAL, "param_index[%d] = %d outside [0,%d)", j, param_index[j], e->P.d);
+    u.names.push_back(param_names[j]);
+    u.index.push_back(param_index[j]);
+  }
+  std::string err;
+  if (rtc_prepare_expr(expr, u.names, "x", &u.expr, &err) != 0)
+    return fail(MHX_EINVAL, "%s", err.c_str());
+  FnDesc& f = e->P.fn[k];
+  f.model = MHX_MODEL_EXPR;
+  f.n_idx = n_index;
+  for (int j = 0; j < n_index; ++j) f.idx[j] = param_index[j];
+  for (int i = 0; i < 4; ++i) f.shape[i] = 0;
+  e->fn_expr[k] = u;
+  e->fn_set[k] = true;
+  e->problem_dirty = true;
+  return MHX_OK;
+}
+
+int mhx_set_prior_expr(mhx_engine* e, int k, const char* expr, const char* const* names,
+                       const int32_t* index, int n) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  if (k < 0 || k >= e->P.K) return fail(MHX_EINVAL, "function index %d out of range", k);
+  if (!expr || !*expr) {  // back to the plain bounds-total body
+    e->prior_expr[k] = UserExpr();
+    e->problem_dirty = true;
+    return MHX_OK;
+  }
+  if (n < 0 || n > MHX_MAX_PARAMS || (n > 0 && (!names || !index)))
+    return fail(MHX_EINVAL, "n must be in [0,%d]", MHX_MAX_PARAMS);
+  UserExpr u;
+  for (int j = 0; j < n; ++j) {
+    if (!valid_ident(names[j])) return fail(MHX_EINVAL, "name %d is not an identifier", j);
+    if (index[j] < 0 || index[j] >= e->P.d)
+      return fail(MHX_EINVAL, "index[%d] = %d outside [0,%d)", j, index[j], e->P.d);
+    u.names.push_back(names[j]);
+    u.index.push_back(index[j]);
+  }
+  std::string err;
+  if (rtc_prepare_expr(expr, u.names, "bounds_total", &u.expr, &err) != 0)
+    return fail(MHX_EINVAL, "%s", err.c_str());
+  e->prior_expr[k] = u;
+  e->problem_dirty = true;
+  return MHX_OK;
+}
+
 int mhx_init_chains(mhx_engine* e, const double* theta0, int broadcast) {
   if (!e || !theta0) return fail(MHX_EINVAL, "engine/theta0 is NULL");
   int rc = use_device(e);
@@ -525,7 +647,7 @@ int mhx_init_chains(mhx_engine* e, const double* theta0, int broadcast) {
   } else {
     HIP_TRY(hipMemcpy(e->theta.p, theta0, (size_t)C * d * sizeof(double), hipMemcpyHostToDevice));
   }
-  HIP_TRY(launch_init(e->spec, e->stream, e->dP.p, e->S));
+  HIP_TRY(do_init(e));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->launches++;
   e->chains_ready = true;
@@ -545,7 +667,7 @@ int mhx_logpost(mhx_engine* e, const double* theta, size_t n, double* out, doubl
       dparts.alloc(2 * n, false) != hipSuccess)
     return fail(MHX_ENOMEM, "hipMalloc for %zu parameter vectors failed", n);
   HIP_TRY(hipMemcpy(dth.p, theta, n * d * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(launch_logpost(e->spec, e->stream, e->dP.p, dth.p, (int64_t)n, dout.p, dparts.p));
+  HIP_TRY(do_logpost(e, dth.p, (int64_t)n, dout.p, dparts.p));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->launches++;
   HIP_TRY(hipMemcpy(out, dout.p, n * sizeof(double), hipMemcpyDeviceToHost));
@@ -572,8 +694,7 @@ int mhx_step_injected(mhx_engine* e, const double* L, int per_chain_l, const dou
   HIP_TRY(hipMemcpy(dz.p, z, C * d * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(du.p, u, C * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dT.p, T, C * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(launch_step_injected(e->spec, e->stream, e->dP.p, e->S, dL.p, per_chain_l, dz.p, du.p,
-                               dT.p, dacc.p));
+  HIP_TRY(do_step_injected(e, dL.p, per_chain_l, dz.p, du.p, dT.p, dacc.p));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->launches++;
   if (accepted_out) HIP_TRY(hipMemcpy(accepted_out, dacc.p, C, hipMemcpyDeviceToHost));

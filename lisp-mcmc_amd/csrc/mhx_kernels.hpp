@@ -1,0 +1,992 @@
+// mhx_kernels.hip -- hand-written gfx950 kernels of the walker-adaptive-steps path.
+//
+//   k_logpost        walker-make-step's prob for a batch of parameter vectors  (M:1067-1070)
+//   k_init           first step of every chain                                 (M:1148-1163)
+//   k_step_injected  one walker-take-step per chain with the caller's z, u, T  (M:1072-1095)
+//   k_adaptive       the do loop of walker-adaptive-steps-full, fused          (M:902-942)
+//   k_acceptance     (walker-get :get :acceptance :take n)                     (M:506-508)
+//
+// One wavefront = one chain.  The 64 lanes split the data points of the likelihood sum
+// (M:400); the kWavesPerGroup chains of a workgroup stream the same dataset in lock step
+// through double-buffered LDS tiles; the per-chain sum is a wavefront butterfly.  Per point the
+// kernel does ~50 binary64 VALU operations on 24 B of data that is L2/MALL resident, so the
+// path is fp64-VALU bound, not a contraction: no MFMA.
+#pragma once
+#ifndef __HIPCC_RTC__  // hiprtc pre-includes the runtime header
+#include <hip/hip_runtime.h>
+#endif
+
+#include "mhx_device.hpp"
+
+namespace mhx {
+
+struct GroupLds {
+  double tiles[2][kMaxArrays][kTilePoints];        // 64 KiB
+  double prop[kWavesPerGroup][MHX_MAX_PARAMS];     // proposal theta' of each wave, 4 KiB
+  double prm[kWavesPerGroup][MHX_MAX_FN_PARAMS + 4];
+};
+
+// ------------------------------------------------------------------------------------------
+// LDS tile pipeline + per-lane accumulation of one function's likelihood sum
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(3))) double* lds_dptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+// Tile t of every array of function f -> LDS buffer `buf`, by LDS-DMA (global_load_lds_dwordx4:
+// no VGPR staging; each wave instruction lands 64 x 16 B = 1 KiB contiguously at a
+// wave-uniform LDS base).  Asynchronous: retired by the s_waitcnt vmcnt(0) the compiler puts in
+// front of the next __syncthreads().
+template <int NARR>
+__device__ __forceinline__ void tile_dma(const FnDesc& f, int64_t t, GroupLds& lds, int buf,
+                                         int w) {
+  const int64_t base = t * kTilePoints + 2 * (int)threadIdx.x;
+  const int wbase = 2 * kWave * w;  // first element this wave fills
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)(f.x + base), (lds_ptr_t)&lds.tiles[buf][0][wbase],
+                                   16, 0, 0);
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)(f.y + base), (lds_ptr_t)&lds.tiles[buf][1][wbase],
+                                   16, 0, 0);
+  if constexpr (NARR > 2)
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(f.w + base),
+                                     (lds_ptr_t)&lds.tiles[buf][2][wbase], 16, 0, 0);
+  if constexpr (NARR > 3)
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(f.c + base),
+                                     (lds_ptr_t)&lds.tiles[buf][3][wbase], 16, 0, 0);
+}
+
+// Sum over the points of function f.  Collective over the workgroup (barriers inside);
+// waves with active == false only help to move tiles.
+template <class Model, int LIK, bool FAST = false>
+__device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::Prep& prep,
+                                        bool active, GroupLds& lds) {
+  constexpr int NARR = LIK == MHX_LIK_POISSON ? 2 : (LIK == MHX_LIK_NORMAL_CUTOFF ? 4 : 3);
+  static_assert(kTilePoints == 2 * kThreads, "one double2 per thread per array per tile");
+  const int l = lane_id();
+  const int w = wave_in_group();
+  const int64_t nt = f.n_tiles;
+  double acc0 = 0.0, acc1 = 0.0;
+  if (nt == 0) return 0.0;
+  tile_dma<NARR>(f, 0, lds, 0, w);
+  // An LDS-DMA is ordered for the readers only by the ISSUING wave's vmcnt wait followed by a
+  // barrier: written out here, never left to the compiler's handling of __syncthreads().
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int64_t t = 0; t < nt; ++t) {
+    const int buf = (int)(t & 1);
+    // buffer buf^1 was last read in iteration t-1, which every wave left through the barrier
+    if (t + 1 < nt) tile_dma<NARR>(f, t + 1, lds, buf ^ 1, w);
+    if (active) {
+      const double* tx = lds.tiles[buf][0];
+      const double* ty = lds.tiles[buf][1];
+      const double* tw = lds.tiles[buf][2];
+      const double* tc = lds.tiles[buf][3];
+      const int64_t gbase = t * kTilePoints;
+      if constexpr (LIK == MHX_LIK_NORMAL) {
+        // software-pipelined: the LDS reads of the next two points are issued before the
+        // ~76 dependent fp64 instructions of the current two, so no wave waits on lgkmcnt
+        double xa = tx[l], xb = tx[l + kWave], ya = ty[l], yb = ty[l + kWave];
+        double wa = tw[l], wb = tw[l + kWave];
+#pragma unroll
+        for (int k = 0; k < kTilePoints / kWave; k += 2) {
+          double xn = 0, xm = 0, yn = 0, ym = 0, wn = 0, wm = 0;
+          if (k + 2 < kTilePoints / kWave) {
+            const int j = (k + 2) * kWave + l;
+            xn = tx[j]; xm = tx[j + kWave];
+            yn = ty[j]; ym = ty[j + kWave];
+            wn = tw[j]; wm = tw[j + kWave];
+          }
+          __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the arithmetic below
+          const double m0 = model_eval<Model, FAST>(prep, xa);
+          const double m1 = model_eval<Model, FAST>(prep, xb);
+          const double r0 = __builtin_fma(-m0, wa, ya), r1 = __builtin_fma(-m1, wb, yb);
+          acc0 = __builtin_fma(r0, r0, acc0);
+          acc1 = __builtin_fma(r1, r1, acc1);
+          xa = xn; xb = xm; ya = yn; yb = ym; wa = wn; wb = wm;
+        }
+      } else
+#pragma unroll 2
+      for (int k = 0; k < kTilePoints / kWave; k += 2) {
+        const int i0 = k * kWave + l, i1 = i0 + kWave;
+        const double x0 = tx[i0], x1 = tx[i1];
+        const double y0 = ty[i0], y1 = ty[i1];
+        const double m0 = model_eval<Model, FAST>(prep, x0);
+        const double m1 = model_eval<Model, FAST>(prep, x1);
+        if (LIK == MHX_LIK_NORMAL) {
+          // the y array holds y/sigma (host, once): r = y/sigma - m/sigma in one fma
+          const double r0 = __builtin_fma(-m0, tw[i0], y0), r1 = __builtin_fma(-m1, tw[i1], y1);
+          acc0 = __builtin_fma(r0, r0, acc0);
+          acc1 = __builtin_fma(r1, r1, acc1);
+        } else if (LIK == MHX_LIK_NORMAL_CUTOFF) {
+          const double r0 = __builtin_fma(-m0, tw[i0], y0), r1 = __builtin_fma(-m1, tw[i1], y1);
+          const double t0 = __builtin_fma(-0.5 * r0, r0, tc[i0]);
+          const double t1 = __builtin_fma(-0.5 * r1, r1, tc[i1]);
+          acc0 = acc0 + (t0 > -5000.0 ? t0 : -5000.0);  // (max -5000d0 term) M:426
+          acc1 = acc1 + (t1 > -5000.0 ? t1 : -5000.0);
+          // pads carry c = 0, w = 0 -> max(-5000, 0) = 0
+        } else {
+          // (- (* k (log lambda)) lambda ...) M:383; pads masked (no neutral pad exists)
+          const double t0 = __builtin_fma(y0, log(m0), -m0);
+          const double t1 = __builtin_fma(y1, log(m1), -m1);
+          acc0 = acc0 + ((gbase + i0) < f.n ? t0 : 0.0);
+          acc1 = acc1 + ((gbase + i1) < f.n ? t1 : 0.0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of tile t+1 has landed
+    __syncthreads();                                   // ... and so has everybody else's
+  }
+  return wave_sum(acc0 + acc1);
+}
+
+template <int LIK>
+__device__ __forceinline__ double finish_lik(const FnDesc& f, double s) {
+  if (LIK == MHX_LIK_NORMAL) return __builtin_fma(-0.5, s, f.lik_const);
+  if (LIK == MHX_LIK_NORMAL_CUTOFF) return s;
+  return s + f.lik_const;
+}
+
+// A problem whose K functions all use one compiled model and likelihood
+template <class Model, int LIK>
+struct FixedSpec {
+  template <class PF>
+  static __device__ __forceinline__ double loglik(const FnDesc& f, PF pf, bool active,
+                                                  GroupLds& lds, double*) {
+    typename Model::Prep prep = Model::prepare(pf, f);
+    if constexpr (model_has_fast<Model>::value) {
+      // uniform over the WORKGROUP only if every wave takes the same branch: the barriers
+      // inside sweep() are workgroup-wide, so the choice is voted
+      const bool fast = __syncthreads_and(!active || Model::fast_ok(prep)) != 0;
+      if (fast) return finish_lik<LIK>(f, sweep<Model, LIK, true>(f, prep, active, lds));
+    }
+    return finish_lik<LIK>(f, sweep<Model, LIK, false>(f, prep, active, lds));
+  }
+  static __device__ __forceinline__ double logprior(const FnDesc&, const double*, double bt) {
+    return bt;
+  }
+};
+
+// Anything else: wave-uniform dispatch on (model, shape, likelihood)
+struct GenericSpec {
+  static __device__ __forceinline__ double logprior(const FnDesc&, const double*, double bt) {
+    return bt;
+  }
+  template <class Model, class PF>
+  static __device__ __forceinline__ double by_lik(const FnDesc& f, PF pf, bool active, GroupLds& lds) {
+    typename Model::Prep prep = Model::prepare(pf, f);
+    switch (f.lik) {
+      case MHX_LIK_NORMAL:
+        return finish_lik<MHX_LIK_NORMAL>(f, sweep<Model, MHX_LIK_NORMAL>(f, prep, active, lds));
+      case MHX_LIK_NORMAL_CUTOFF:
+        return finish_lik<MHX_LIK_NORMAL_CUTOFF>(
+            f, sweep<Model, MHX_LIK_NORMAL_CUTOFF>(f, prep, active, lds));
+      default:
+        return finish_lik<MHX_LIK_POISSON>(f, sweep<Model, MHX_LIK_POISSON>(f, prep, active, lds));
+    }
+  }
+  template <class Model, class PF>
+  static __device__ __forceinline__ double by_lik_dyn(const FnDesc& f, PF pf, bool active,
+                                                   GroupLds& lds, double* scratch) {
+    typename Model::Prep prep = Model::prepare(pf, f, scratch);
+    __builtin_amdgcn_wave_barrier();
+    switch (f.lik) {
+      case MHX_LIK_NORMAL:
+        return finish_lik<MHX_LIK_NORMAL>(f, sweep<Model, MHX_LIK_NORMAL>(f, prep, active, lds));
+      case MHX_LIK_NORMAL_CUTOFF:
+        return finish_lik<MHX_LIK_NORMAL_CUTOFF>(
+            f, sweep<Model, MHX_LIK_NORMAL_CUTOFF>(f, prep, active, lds));
+      default:
+        return finish_lik<MHX_LIK_POISSON>(f, sweep<Model, MHX_LIK_POISSON>(f, prep, active, lds));
+    }
+  }
+  template <class PF>
+  static __device__ __forceinline__ double loglik(const FnDesc& f, PF pf, bool active,
+                                                  GroupLds& lds, double* scratch) {
+    switch (f.model) {
+      case MHX_MODEL_POLY:
+        return by_lik_dyn<PolyModelDyn>(f, pf, active, lds, scratch);
+      case MHX_MODEL_GAUSS_PEAKS:
+        return by_lik_dyn<PeaksModelDyn<false>>(f, pf, active, lds, scratch);
+      case MHX_MODEL_LORENTZ_PEAKS:
+        return by_lik_dyn<PeaksModelDyn<true>>(f, pf, active, lds, scratch);
+      case MHX_MODEL_LORDER_MIXED:
+        return by_lik<LorderModel>(f, pf, active, lds);
+      case MHX_MODEL_EXP_DECAY:
+        return by_lik<ExpDecayModel>(f, pf, active, lds);
+      case MHX_MODEL_SINUSOID:
+        return by_lik<SinusoidModel>(f, pf, active, lds);
+      default:
+        return by_lik<PVoigt2Model>(f, pf, active, lds);
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// prior-bounds-let (M:346-369) and the posterior sum of walker-make-step (M:1067-1070)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double bound_penalty(double p, double lo, double hi) {
+  if (lo < p && p < hi) return 0.0;
+  const double a = fabs(p - hi), b = fabs(p - lo);
+  const double m = a < b ? a : b;
+  return -1e10 * (exp(m * 1e-5) - 1.0);
+}
+__device__ __forceinline__ double logprior_fn(const FnDesc& f, const double* theta) {
+  double acc = 0.0;
+  for (int i = 0; i < f.n_bounds; ++i) {
+    const int ix = f.bidx[i];
+    const double v = ix >= 0 ? theta[ix] : 0.0;  // (getf params key 0d0) M:353
+    const double b = bound_penalty(v, f.blo[i], f.bhi[i]);
+    acc = i == 0 ? b : acc + b;
+  }
+  return acc;
+}
+
+// theta' of this wave is in lds.prop[w]; collective over the workgroup
+template <class Spec>
+__device__ __forceinline__ double group_logpost(const ProblemDesc& P, bool active, GroupLds& lds,
+                                                int w, double* ll_out, double* lp_out) {
+  __syncthreads();  // proposals written, previous users of the tile buffers are done
+  double ll = 0.0, lp = 0.0;
+  const double* th = lds.prop[w];
+  for (int k = 0; k < P.K; ++k) {
+    const FnDesc& f = P.fn[k];
+    auto pf = [&](int j) -> double { return th[f.idx[j]]; };
+    const double v = Spec::loglik(f, pf, active, lds, lds.prm[w]);
+    ll = k == 0 ? v : ll + v;
+    // Spec::logprior lets a user prior body add terms to bounds-total (M:366-369)
+    const double q = Spec::logprior(f, th, logprior_fn(f, th));
+    lp = k == 0 ? q : lp + q;
+  }
+  *ll_out = ll;
+  *lp_out = lp;
+  return ll + lp;
+}
+
+// ------------------------------------------------------------------------------------------
+// walker-get on the device ring (newest first = entries nh-1, nh-2, ...)
+// ------------------------------------------------------------------------------------------
+struct Ring {
+  const double* prob;   // this chain's [R]
+  const double* theta;  // this chain's [R][d]
+  int64_t nh;           // entries ever pushed
+  int64_t length;       // (walker-length w)
+  int mask;             // R - 1
+  int d;
+  __device__ __forceinline__ int window(int take) const {
+    return (int)(length < (int64_t)take ? length : (int64_t)take);
+  }
+  __device__ __forceinline__ int slot(int s) const { return (int)((nh - 1 - s) & mask); }
+};
+
+__device__ __forceinline__ unsigned long long bits_of(double v) {
+  return (unsigned long long)__double_as_longlong(v);
+}
+
+// M:506-508 with remove-consecutive-duplicates (M:220-223); eql on doubles = same bits
+__device__ __forceinline__ void ring_acceptance(const Ring& r, int take, int* num, int* den) {
+  const int t = r.window(take), l = lane_id();
+  int runs = 0;
+  for (int s = l; s < t; s += kWave) {
+    const bool last = s == t - 1;
+    const double a = r.prob[r.slot(s)];
+    const double b = last ? 0.0 : r.prob[r.slot(s + 1)];
+    runs += (last || bits_of(a) != bits_of(b)) ? 1 : 0;
+  }
+  *num = wave_sum_i(runs);
+  *den = t;
+}
+// rational acceptance num/den against the single-float literals of M:898, M:911, M:930-941
+__device__ __forceinline__ bool acc_lt(int num, int den, float f) {
+  return (double)num < (double)f * (double)den;
+}
+__device__ __forceinline__ bool acc_gt(int num, int den, float f) {
+  return (double)num > (double)f * (double)den;
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const double o = __shfl_xor(v, m, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// stable-probs-p M:880-885 over (walker-get :log-liklihoods :take steps-to-settle)
+__device__ __forceinline__ bool ring_stable_probs(const Ring& r, int sts) {
+  const int t = r.window(sts), l = lane_id();
+  if (t < 200) return false;
+  const double kInf = __builtin_inf();
+  double early = -kInf, late = -kInf, mn = kInf;
+  for (int s = l; s < t; s += kWave) {
+    const double v = r.prob[r.slot(s)];
+    if (s < 200 && v > early) early = v;
+    if (s >= t - 200 && v > late) late = v;
+    if (v < mn) mn = v;
+  }
+  early = wave_max(early);
+  late = wave_max(late);
+  mn = -wave_max(-mn);
+  const double spread = early - mn;
+  return fabs(early - late) < 0.5 && 4.0 < spread && spread < 9.0;
+}
+
+enum { L_OK = 0, L_CAUGHT = 1, L_INVALID = 2, L_EMPTY = 3 };
+// With finite inputs an inf is an overflow trap and a NaN can only follow an earlier overflow
+// (inf - inf), so any non-finite result means floating-point-overflow was signalled first:
+// caught by the handler-case of M:891-894.  Only the explicit 0/0 of M:597 is invalid.
+__device__ __forceinline__ int trap_of(double r) { return finite_f64(r) ? L_OK : L_CAUGHT; }
+
+// (walker-get :get :l-matrix :take take) M:543 = Cholesky of the population covariance of the
+// displacements between successive forward steps.  fwd: int scratch [>= take]; cov, Lout:
+// double scratch [d*d]; avg: LDS scratch [d].  Returns L_* (uniform).
+// forward steps M:497-502 of the newest `take` steps, newest first, compacted in order into
+// fwd[] (ring slots); returns their number (uniform)
+__device__ __forceinline__ int ring_forward_list(const Ring& r, int take, int* fwd) {
+  const int t = r.window(take), l = lane_id();
+  int nf = 0;
+  for (int base = 0; base < t - 1; base += kWave) {
+    const int s = base + l;
+    bool f = false;
+    if (s < t - 1) {
+      const double a = r.prob[r.slot(s)], b = r.prob[r.slot(s + 1)];
+      f = !(a <= b);
+    }
+    const unsigned long long m = __ballot(f);
+    const int pos = nf + __popcll(m & ((1ULL << l) - 1ULL));
+    if (f) fwd[pos] = r.slot(s);
+    nf += __popcll(m);
+  }
+  return nf;
+}
+
+// cholesky-decomp M:583-598 by ONE lane in the reference's loop order (diagonal
+// sqrt(max 0 .), upper triangle 0).  Returns L_OK / L_CAUGHT (x/0, overflow) / L_INVALID (0/0).
+__device__ __forceinline__ int cholesky_seq(const double* cov, double* Lout, int d) {
+  int cst = L_OK;
+  for (int e = 0; e < d * d; ++e) Lout[e] = 0.0;
+  for (int i = 0; i < d && cst == L_OK; ++i)
+    for (int k = 0; k <= i && cst == L_OK; ++k) {
+      double tmp = 0.0;
+      for (int j = 0; j < k; ++j) tmp = tmp + Lout[i * d + j] * Lout[k * d + j];
+      cst = trap_of(tmp);
+      if (cst != L_OK) break;
+      if (i == k) {
+        const double a = cov[i * d + k] - tmp;
+        Lout[i * d + k] = ieee_sqrt(a > 0.0 ? a : 0.0);  // (sqrt (max 0d0 a)) M:596
+      } else {
+        const double num = cov[i * d + k] - tmp, den = Lout[k * d + k];
+        if (den == 0.0) {
+          cst = num == 0.0 ? L_INVALID : L_CAUGHT;
+        } else {
+          const double q = num / den;
+          cst = trap_of(q);
+          Lout[i * d + k] = q;
+        }
+      }
+    }
+  return cst;
+}
+
+__device__ __noinline__ int ring_l_matrix(const Ring& r, int take, int* fwd, double* cov,
+                                          double* Lout, lds_dptr_t avg, int* n_forward) {
+  const int l = lane_id(), d = r.d;
+  const int nf = ring_forward_list(r, take, fwd);
+  *n_forward = nf;
+  if (nf == 0) return L_CAUGHT;  // (elt nil 0): an index error is a type-error
+  if (nf == 1) return L_EMPTY;
+  __threadfence();
+  const int M = nf - 1;
+  const double dM = (double)M;
+  // diff-lplist M:277-280: older - newer of consecutive forward steps
+  auto diff = [&](int k, int p) -> double {
+    return r.theta[(int64_t)fwd[k + 1] * d + p] - r.theta[(int64_t)fwd[k] * d + p];
+  };
+  // averages M:626: (/ (reduce #'+ x) n)
+  int st = L_OK, first_bad = 0x7fffffff;
+  if (l < d) {
+    double s = diff(0, l);
+    for (int k = 1; k < M; ++k) s = s + diff(k, l);
+    const double a = s / dM;
+    avg[l] = a;
+    st = trap_of(a);
+    if (st != L_OK) first_bad = l;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // covariance M:636-643 (the /n sits inside the accumulation)
+  for (int e = l; e < d * d; e += kWave) {
+    const int i = e / d, j = e - i * d;
+    const double ai = avg[i], aj = avg[j];
+    double mini = 0.0;
+    for (int k = 0; k < M; ++k) {
+      const double x = diff(k, i) - ai, y = diff(k, j) - aj;
+      mini = mini + (x * y) / dM;
+    }
+    cov[e] = mini;
+    if (st == L_OK) {
+      st = trap_of(mini);
+      if (st != L_OK) first_bad = d + e;
+    }
+  }
+  // the first failing operation in the reference's order decides which condition is raised
+  int fb = first_bad;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const int o = __shfl_xor(fb, m, 64);
+    fb = o < fb ? o : fb;
+  }
+  if (fb != 0x7fffffff) {
+    const unsigned long long who = __ballot(first_bad == fb);
+    const int src = __ffsll((long long)who) - 1;
+    return __builtin_amdgcn_readlane(st, src);
+  }
+  __threadfence();
+  // cholesky-decomp M:583-598, one lane, the reference's loop order
+  int cst = L_OK;
+  if (l == 0) cst = cholesky_seq(cov, Lout, d);
+  cst = __builtin_amdgcn_readfirstlane(cst);
+  __threadfence();
+  return cst;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) unsigned char mhx_lds_raw[];
+
+template <class Spec>
+__device__ __forceinline__ void k_init_body(const ProblemDesc* __restrict__ Pp, ChainState S);
+template <class Spec>
+__device__ __forceinline__ void k_step_injected_body(
+    const ProblemDesc* __restrict__ Pp, ChainState S, const double* __restrict__ Lin,
+    int per_chain_l, const double* __restrict__ z, const double* __restrict__ u,
+    const double* __restrict__ T, unsigned char* __restrict__ accepted);
+template <class Spec>
+__device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ Pp, ChainState S,
+                                                RunDesc R, int64_t max_iters, int plain);
+
+// Every Spec-dependent kernel is a __device__ body + a thin __global__ template, so that the
+// run-time compiled user-expression kernels (mhx_rtc.cpp) can wrap the same bodies.
+template <class Spec>
+__device__ __forceinline__ void k_logpost_body(const ProblemDesc* __restrict__ Pp,
+                                               const double* __restrict__ theta, int64_t n,
+                                               double* __restrict__ out,
+                                               double* __restrict__ parts) {
+  GroupLds& lds = *reinterpret_cast<GroupLds*>(mhx_lds_raw);
+  const ProblemDesc& P = *Pp;
+  const int w = wave_in_group(), l = lane_id(), d = P.d;
+  const int64_t c = (int64_t)blockIdx.x * kWavesPerGroup + w;
+  const bool valid = c < n;
+  if (l < d) lds.prop[w][l] = valid ? theta[c * d + l] : 0.0;
+  double ll, lp;
+  const double v = group_logpost<Spec>(P, valid, lds, w, &ll, &lp);
+  if (valid && l == 0) {
+    out[c] = v;
+    if (parts) {
+      parts[2 * c] = ll;
+      parts[2 * c + 1] = lp;
+    }
+  }
+}
+template <class Spec>
+__global__ __launch_bounds__(kThreads) void k_logpost(const ProblemDesc* __restrict__ Pp,
+                                                      const double* __restrict__ theta, int64_t n,
+                                                      double* __restrict__ out,
+                                                      double* __restrict__ parts) {
+  k_logpost_body<Spec>(Pp, theta, n, out, parts);
+}
+
+// walker-create's first step (M:1148-1163): prob, walk = (first-step), length 1, age 1
+template <class Spec>
+__global__ __launch_bounds__(kThreads) void k_init(const ProblemDesc* __restrict__ Pp,
+                                                   ChainState S) {
+  k_init_body<Spec>(Pp, S);
+}
+template <class Spec>
+__device__ __forceinline__ void k_init_body(const ProblemDesc* __restrict__ Pp, ChainState S) {
+  GroupLds& lds = *reinterpret_cast<GroupLds*>(mhx_lds_raw);
+  const ProblemDesc& P = *Pp;
+  const int w = wave_in_group(), l = lane_id(), d = P.d;
+  const int64_t c = (int64_t)blockIdx.x * kWavesPerGroup + w;
+  const bool valid = c < S.n_chains;
+  const double th = (valid && l < d) ? S.theta[c * d + l] : 0.0;
+  if (l < d) lds.prop[w][l] = th;
+  double ll, lp;
+  const double v = group_logpost<Spec>(P, valid, lds, w, &ll, &lp);
+  if (!valid) return;
+  if (l < d) {
+    S.best_theta[c * d + l] = th;
+    S.hist_theta[(c * S.R + 0) * d + l] = th;
+  }
+  if (l == 0) {
+    S.prob[c] = v;
+    S.best_prob[c] = v;
+    S.hist_prob[c * S.R + 0] = v;
+    S.n_hist[c] = 1;
+    S.length[c] = 1;
+    S.age[c] = 1;
+    S.draw[c] = 0;
+    S.status[c] = finite_f64(v) ? MHX_CHAIN_DONE : MHX_CHAIN_FP_TRAP;
+    S.loop_i[c] = 0;
+    S.shutting[c] = 0;
+    S.temperature[c] = 1.0;
+    S.reset_index[c] = 10000;
+  }
+}
+
+// per-wave registers of one chain
+struct ChainRegs {
+  double th;      // theta_j in lane j
+  double best_th;
+  double prob0, best_prob, T;
+  int64_t nh, length, age, loop_i, reset_index;
+  uint64_t draw;
+  int shutting, status;
+};
+
+__device__ __forceinline__ void chain_load(const ChainState& S, int64_t c, int d, ChainRegs& r) {
+  const int l = lane_id();
+  r.th = l < d ? S.theta[c * d + l] : 0.0;
+  r.best_th = l < d ? S.best_theta[c * d + l] : 0.0;
+  r.prob0 = uniform_f64(S.prob[c]);
+  r.best_prob = uniform_f64(S.best_prob[c]);
+  r.T = uniform_f64(S.temperature[c]);
+  r.nh = uniform_i64(S.n_hist[c]);
+  r.length = uniform_i64(S.length[c]);
+  r.age = uniform_i64(S.age[c]);
+  r.loop_i = uniform_i64(S.loop_i[c]);
+  r.reset_index = uniform_i64(S.reset_index[c]);
+  r.draw = (uint64_t)uniform_i64((int64_t)S.draw[c]);
+  r.shutting = __builtin_amdgcn_readfirstlane(S.shutting[c]);
+  r.status = __builtin_amdgcn_readfirstlane(S.status[c]);
+}
+__device__ __forceinline__ void chain_store(const ChainState& S, int64_t c, int d,
+                                            const ChainRegs& r) {
+  const int l = lane_id();
+  if (l < d) {
+    S.theta[c * d + l] = r.th;
+    S.best_theta[c * d + l] = r.best_th;
+  }
+  if (l == 0) {
+    S.prob[c] = r.prob0;
+    S.best_prob[c] = r.best_prob;
+    S.temperature[c] = r.T;
+    S.n_hist[c] = r.nh;
+    S.length[c] = r.length;
+    S.age[c] = r.age;
+    S.loop_i[c] = r.loop_i;
+    S.reset_index[c] = r.reset_index;
+    S.draw[c] = r.draw;
+    S.shutting[c] = r.shutting;
+    S.status[c] = r.status;
+  }
+}
+
+// get-covariant-sample M:679-700: lane i forms sum_j L_ij z_j from 0d0 (multiply, then add),
+// then adds theta_i.  z_j sits in lane j of zv.
+__device__ __forceinline__ double propose(const double* L, int d, double zv, double th) {
+  const int l = lane_id();
+  double mini = 0.0;
+  for (int j = 0; j < d; ++j) {
+    const double zj = readlane_f64(zv, j);
+    const double lij = l < d ? L[l * d + j] : 0.0;
+    mini = mini + lij * zj;
+  }
+  return mini + th;
+}
+
+// walker-modify :add-step M:549-555 on the ring
+__device__ __forceinline__ void add_step(const ChainState& S, int64_t c, int d, ChainRegs& r) {
+  const int l = lane_id();
+  const int64_t slot = r.nh & (int64_t)(S.R - 1);
+  if (l < d) S.hist_theta[(c * S.R + slot) * d + l] = r.th;
+  if (l == 0) S.hist_prob[c * S.R + slot] = r.prob0;
+  r.nh++;
+  r.length++;
+  r.age++;
+  if (r.prob0 > r.best_prob) {
+    r.best_prob = r.prob0;
+    r.best_th = r.th;
+  }
+}
+
+// accept test of M:1091-1092; log u is evaluated only when the first clause fails in the
+// reference (short-circuit `or`); the value of the test is the same either way
+__device__ __forceinline__ bool mh_accept(double prob1, double prob0, double T, double u) {
+  return (prob1 > prob0) || ((prob1 - prob0) / T > det_log(u));
+}
+
+template <class Spec>
+__global__ __launch_bounds__(kThreads) void k_step_injected(
+    const ProblemDesc* __restrict__ Pp, ChainState S, const double* __restrict__ Lin,
+    int per_chain_l, const double* __restrict__ z, const double* __restrict__ u,
+    const double* __restrict__ T, unsigned char* __restrict__ accepted) {
+  k_step_injected_body<Spec>(Pp, S, Lin, per_chain_l, z, u, T, accepted);
+}
+template <class Spec>
+__device__ __forceinline__ void k_step_injected_body(
+    const ProblemDesc* __restrict__ Pp, ChainState S, const double* __restrict__ Lin,
+    int per_chain_l, const double* __restrict__ z, const double* __restrict__ u,
+    const double* __restrict__ T, unsigned char* __restrict__ accepted) {
+  GroupLds& lds = *reinterpret_cast<GroupLds*>(mhx_lds_raw);
+  const ProblemDesc& P = *Pp;
+  const int w = wave_in_group(), l = lane_id(), d = P.d;
+  const int64_t c = (int64_t)blockIdx.x * kWavesPerGroup + w;
+  const bool valid = c < S.n_chains;
+  ChainRegs r;
+  double thp = 0.0;
+  bool run = false;
+  if (valid) {
+    chain_load(S, c, d, r);
+    run = r.status != MHX_CHAIN_FP_TRAP;
+    const double zv = l < d ? z[c * d + l] : 0.0;
+    thp = propose(Lin + (per_chain_l ? c * d * d : 0), d, zv, r.th);
+    if (l < d) lds.prop[w][l] = thp;
+  }
+  double ll, lp;
+  const double prob1 = group_logpost<Spec>(P, valid && run, lds, w, &ll, &lp);
+  if (!valid || !run) return;
+  int acc = 0;
+  if (!finite_f64(prob1)) {
+    r.status = MHX_CHAIN_FP_TRAP;  // the reference would have signalled (traps enabled)
+  } else {
+    const double uu = uniform_f64(u[c]), TT = uniform_f64(T[c]);
+    // here the caller's u stands for (random 1.0d0); log as the runtime's libm would
+    acc = (prob1 > r.prob0) || ((prob1 - r.prob0) / TT > log(uu));
+    if (acc) {
+      r.th = thp;
+      r.prob0 = prob1;
+    }
+    add_step(S, c, d, r);
+  }
+  if (accepted && l == 0) accepted[c] = (unsigned char)acc;
+  if (l == 0 && r.status != MHX_CHAIN_FP_TRAP) atomicAdd(S.step_counter, 1ULL);
+  chain_store(S, c, d, r);
+}
+
+__device__ __forceinline__ int64_t floor_mod(int64_t a, int64_t b) {
+  const int64_t m = a % b;
+  return m < 0 ? m + b : m;
+}
+
+// The do loop of walker-adaptive-steps-full (M:902-942), up to max_iters iterations for each
+// chain of the workgroup.  plain != 0: walker-many-steps (M:849-853): constant L, T = 1.
+template <class Spec>
+__global__ __launch_bounds__(kThreads, 4) void k_adaptive(const ProblemDesc* __restrict__ Pp,
+                                                       ChainState S, RunDesc R,
+                                                       int64_t max_iters, int plain) {
+  k_adaptive_body<Spec>(Pp, S, R, max_iters, plain);
+}
+template <class Spec>
+__device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ Pp, ChainState S,
+                                                RunDesc R, int64_t max_iters, int plain) {
+  GroupLds& lds = *reinterpret_cast<GroupLds*>(mhx_lds_raw);
+  const ProblemDesc& P = *Pp;
+  const int w = wave_in_group(), l = lane_id(), d = P.d;
+  const int64_t c = (int64_t)blockIdx.x * kWavesPerGroup + w;
+  const bool valid = c < S.n_chains;
+  ChainRegs r;
+  r.status = MHX_CHAIN_DONE;
+  if (valid) chain_load(S, c, d, r);
+  double* Lc = S.L + (valid ? c : 0) * d * d;
+  const uint64_t gchain = (uint64_t)(S.chain_offset + c);
+  Ring ring;
+  ring.prob = S.hist_prob + (valid ? c : 0) * S.R;
+  ring.theta = S.hist_theta + (valid ? c : 0) * S.R * d;
+  ring.mask = S.R - 1;
+  ring.d = d;
+  int* fwd = S.fwd_idx + (valid ? c : 0) * R.sts;
+  double* covs = S.mat_tmp + (valid ? c : 0) * 2 * d * d;
+  double* lnew = covs + d * d;
+  const double factor = (2.38 * 2.38) / (double)d;  // (/ (expt 2.38d0 2) num-params) M:890
+  const int64_t age0 = valid ? r.age : 0;
+
+  for (int64_t it = 0; it < max_iters; ++it) {
+    bool running = valid && r.status == MHX_CHAIN_RUNNING;
+    if (running) {
+      if (r.loop_i >= R.n) {  // end test of the do loop, M:904
+        r.status = MHX_CHAIN_DONE;
+        running = false;
+      } else if (__builtin_amdgcn_readfirstlane(*(volatile const int*)R.stop_flag)) {
+        r.status = MHX_CHAIN_STOPPED;  // mfit-walker-estop
+        running = false;
+      }
+    }
+    if (!__syncthreads_or(running ? 1 : 0)) break;
+    double thp = 0.0, u = 1.0;
+    if (running) {
+      if (!plain) {
+        // M:905-917
+        bool shut = !r.shutting && (R.n - r.loop_i) < R.tail;
+        if (!shut && R.auto_mode && !r.shutting && floor_mod(r.loop_i, 1000) == 0 &&
+            r.loop_i > 2 * R.sts) {
+          __threadfence();
+          ring.nh = r.nh;
+          ring.length = r.length;
+          int num, den;
+          ring_acceptance(ring, 1000, &num, &den);
+          if (acc_gt(num, den, 0.2f) && acc_lt(num, den, 0.5f) &&
+              ring_stable_probs(ring, (int)R.sts))
+            shut = true;
+        }
+        if (shut) {
+          r.T = 1.0;
+          r.shutting = 1;
+          r.loop_i = R.n - R.tail;
+        }
+      }
+      // M:918 walker-take-step: proposal
+      const double rv = rng_lane_value(S.seed, gchain, r.draw, d);
+      r.draw++;
+      u = readlane_f64(rv, 63);
+      thp = propose(Lc, d, rv, r.th);
+      if (l < d) lds.prop[w][l] = thp;
+    }
+    double ll, lp;
+    const double prob1 = group_logpost<Spec>(P, running, lds, w, &ll, &lp);
+    if (!running) continue;
+    if (!finite_f64(prob1)) {
+      r.status = MHX_CHAIN_FP_TRAP;
+      continue;
+    }
+    if (mh_accept(prob1, r.prob0, r.T, u)) {
+      r.th = thp;
+      r.prob0 = prob1;
+    }
+    add_step(S, c, d, r);
+    if (plain) {
+      r.loop_i++;
+      continue;
+    }
+    const int64_t i = r.loop_i;
+    // annealing M:920-921
+    if (!r.shutting && i < R.temp_steps) r.T = uniform_f64(R.temps[i]);
+    // cleaning M:923-927 (:keep-walks only shortens what :take can see)
+    if (R.has_mwl && i == r.reset_index) {
+      if (r.length > R.mwl) {
+        r.length = R.mwl;
+        r.reset_index += R.mwl + 1;
+      } else {
+        r.reset_index += 1 + (R.mwl - r.length);
+      }
+    }
+    // regular l-matrix updating M:929-942
+    if (i > 0) {
+      const bool m200 = floor_mod(i, 200) == 0;
+      const bool msts = !r.shutting && floor_mod(i, 2 * R.sts) == 0;
+      if (m200 || msts) {
+        __threadfence();
+        ring.nh = r.nh;
+        ring.length = r.length;
+        int num, den;
+        ring_acceptance(ring, 200, &num, &den);
+        if ((m200 && acc_lt(num, den, 0.2f)) || (m200 && acc_gt(num, den, 0.4f)) || msts) {
+          if (acc_gt(num, den, 0.2f) && acc_lt(num, den, 0.4f)) {
+            int nf;
+            int st;
+            if (R.adapt_mode == MHX_ADAPT_POOLED && *(volatile const int*)S.pool_valid != 0) {
+              // extension: the factor of the covariance pooled over all chains and ranks
+              // (already scaled by 2.38^2/d) replaces the walker's own estimate
+              for (int e = l; e < d * d; e += kWave) Lc[e] = S.L_pool[e];
+              st = L_EMPTY;  // nothing more to do below
+            } else {
+              st = ring_l_matrix(ring, (int)R.sts, fwd, covs, lnew, (lds_dptr_t)lds.prop[w], &nf);
+            }
+            if (st == L_OK) {
+              for (int e = l; e < d * d; e += kWave) Lc[e] = factor * lnew[e];
+            } else if (st == L_CAUGHT) {  // handler-case returns the CURRENT l-matrix, which
+              for (int e = l; e < d * d; e += kWave) Lc[e] = factor * Lc[e];  // scale-array mutates
+            } else if (st == L_INVALID) {
+              r.status = MHX_CHAIN_FP_TRAP;
+            }  // L_EMPTY: 0x0 matrix fails the dimension test of M:936, L kept
+          } else if (acc_lt(num, den, 0.2f)) {
+            for (int e = l; e < d * d; e += kWave) Lc[e] = 0.1 * Lc[e];
+          } else if (acc_gt(num, den, 0.4f)) {
+            for (int e = l; e < d * d; e += kWave) Lc[e] = 1.9 * Lc[e];
+          }
+          __threadfence();
+        }
+      }
+    }
+    if (r.status == MHX_CHAIN_RUNNING) r.loop_i++;
+  }
+  if (valid) {
+    if (r.status == MHX_CHAIN_RUNNING && r.loop_i >= R.n) r.status = MHX_CHAIN_DONE;
+    chain_store(S, c, d, r);
+    if (l == 0 && r.age != age0) atomicAdd(S.step_counter, (unsigned long long)(r.age - age0));
+  }
+}
+
+// Initial L of M:896-901 when the caller gave none.
+__global__ __launch_bounds__(kThreads) void k_initial_l(ChainState S, RunDesc R, int have_l,
+                                                        double T0) {
+  GroupLds& lds = *reinterpret_cast<GroupLds*>(mhx_lds_raw);
+  const int w = wave_in_group(), l = lane_id(), d = S.d;
+  const int64_t c = (int64_t)blockIdx.x * kWavesPerGroup + w;
+  if (c >= S.n_chains) return;
+  double* Lc = S.L + c * d * d;
+  Ring ring;
+  ring.prob = S.hist_prob + c * S.R;
+  ring.theta = S.hist_theta + c * S.R * d;
+  ring.mask = S.R - 1;
+  ring.d = d;
+  ring.nh = uniform_i64(S.n_hist[c]);
+  ring.length = uniform_i64(S.length[c]);
+  if (have_l) {  // :l-matrix given: M:896 skips the whole block
+    if (l == 0) {
+      if (S.status[c] != MHX_CHAIN_FP_TRAP) S.status[c] = MHX_CHAIN_RUNNING;
+      S.loop_i[c] = 1;
+      S.shutting[c] = 0;
+      S.reset_index[c] = 10000;
+      S.temperature[c] = T0;
+    }
+    return;
+  }
+  // (diagonal-covariance (get-plist-values most-likely-params)) M:899
+  for (int e = l; e < d * d; e += kWave) {
+    const int i = e / d, j = e - i * d;
+    Lc[e] = i == j ? S.best_theta[c * d + i] : 0.0;
+  }
+  int num, den;
+  ring_acceptance(ring, 100, &num, &den);
+  int status = MHX_CHAIN_RUNNING;
+  if (!(ring.length < R.sts || acc_lt(num, den, 0.1f))) {
+    __threadfence();
+    int* fwd = S.fwd_idx + c * R.sts;
+    double* covs = S.mat_tmp + c * 2 * d * d;
+    double* lnew = covs + d * d;
+    const double factor = (2.38 * 2.38) / (double)d;
+    int nf;
+    const int st = ring_l_matrix(ring, (int)R.sts, fwd, covs, lnew, (lds_dptr_t)lds.prop[w], &nf);
+    if (st == L_OK) {
+      for (int e = l; e < d * d; e += kWave) Lc[e] = factor * lnew[e];
+    } else if (st == L_CAUGHT) {
+      for (int e = l; e < d * d; e += kWave) Lc[e] = factor * Lc[e];
+    } else {
+      status = MHX_CHAIN_FP_TRAP;  // invalid operation, or a 0x0 l-matrix (M:901 then M:918)
+    }
+  }
+  if (l == 0) {
+    if (S.status[c] != MHX_CHAIN_FP_TRAP) S.status[c] = status;
+    S.loop_i[c] = 1;  // (do ((i 1 (+ i 1))) ...) M:902
+    S.shutting[c] = 0;
+    S.reset_index[c] = 10000;
+    S.temperature[c] = T0;  // (rational temperature) M:876
+  }
+}
+
+// (walker-get w :get :l-matrix :take take) of one chain, with the device code the controller
+// itself runs.  out: [d*d] factor, info[0] = L_* status, info[1] = (length forward-steps)
+__global__ __launch_bounds__(kWave) void k_l_matrix(ChainState S, int64_t c, int take, int* fwd,
+                                                    double* cov, double* out, int* info) {
+  __shared__ double avg[MHX_MAX_PARAMS];
+  Ring ring;
+  ring.prob = S.hist_prob + c * S.R;
+  ring.theta = S.hist_theta + c * S.R * S.d;
+  ring.mask = S.R - 1;
+  ring.d = S.d;
+  ring.nh = uniform_i64(S.n_hist[c]);
+  ring.length = uniform_i64(S.length[c]);
+  int nf = 0;
+  const int st = ring_l_matrix(ring, take, fwd, cov, out, (lds_dptr_t)avg, &nf);
+  if (lane_id() == 0) {
+    info[0] = st;
+    info[1] = nf;
+  }
+}
+
+// ---- pooled adaptive covariance (extension of the north star; not in the reference) --------
+// Step 1: every chain reduces the displacements between its successive forward steps (the
+// vectors lplist-covariance would see, M:543) to (n, sum delta, sum delta delta^T).
+__global__ __launch_bounds__(kThreads) void k_pool_stats(ChainState S, RunDesc R) {
+  const int w = wave_in_group(), l = lane_id(), d = S.d;
+  const int64_t c = (int64_t)blockIdx.x * kWavesPerGroup + w;
+  if (c >= S.n_chains) return;
+  const int E = 1 + d + d * d;
+  double* out = S.pool_stats + c * E;
+  Ring ring;
+  ring.prob = S.hist_prob + c * S.R;
+  ring.theta = S.hist_theta + c * S.R * d;
+  ring.mask = S.R - 1;
+  ring.d = d;
+  ring.nh = uniform_i64(S.n_hist[c]);
+  ring.length = uniform_i64(S.length[c]);
+  int* fwd = S.fwd_idx + c * R.sts;
+  const int nf = S.status[c] == MHX_CHAIN_FP_TRAP ? 0 : ring_forward_list(ring, (int)R.sts, fwd);
+  __threadfence();
+  const int M = nf >= 2 ? nf - 1 : 0;
+  auto diff = [&](int k, int p) -> double {
+    return ring.theta[(int64_t)fwd[k + 1] * d + p] - ring.theta[(int64_t)fwd[k] * d + p];
+  };
+  if (l == 0) out[0] = (double)M;
+  if (l < d) {
+    double s = 0.0;
+    for (int k = 0; k < M; ++k) s = s + diff(k, l);
+    out[1 + l] = s;
+  }
+  for (int e = l; e < d * d; e += kWave) {
+    const int i = e / d, j = e - i * d;
+    double q = 0.0;
+    for (int k = 0; k < M; ++k) q = __builtin_fma(diff(k, i), diff(k, j), q);
+    out[1 + d + e] = q;
+  }
+}
+
+// Step 2: sum over the chains of this rank, one block per entry, fixed order (reproducible)
+__global__ __launch_bounds__(256) void k_pool_reduce(ChainState S) {
+  __shared__ double part[256];
+  const int d = S.d, E = 1 + d + d * d, e = blockIdx.x, t = threadIdx.x;
+  double s = 0.0;
+  for (int64_t c = t; c < S.n_chains; c += 256) s = s + S.pool_stats[c * E + e];
+  part[t] = s;
+  __syncthreads();
+  for (int h = 128; h >= 1; h >>= 1) {
+    if (t < h) part[t] = part[t] + part[t + h];
+    __syncthreads();
+  }
+  if (t == 0) S.pool_vec[e] = part[0];
+}
+
+// Step 3 (after the all-reduce over ranks): covariance, clamped Cholesky, 2.38^2/d scaling
+__global__ __launch_bounds__(kWave) void k_pool_factor(ChainState S) {
+  const int l = lane_id(), d = S.d;
+  const double* v = S.pool_vec;
+  double* cov = S.mat_tmp;  // chain 0's scratch is free between step launches
+  const double n = v[0];
+  int st = L_CAUGHT;
+  if (n >= 2.0) {
+    for (int e = l; e < d * d; e += kWave) {
+      const int i = e / d, j = e - i * d;
+      cov[e] = v[1 + d + e] / n - (v[1 + i] / n) * (v[1 + j] / n);
+    }
+    __threadfence();
+    st = L_OK;
+    if (l == 0) st = cholesky_seq(cov, S.L_pool, d);
+    st = __builtin_amdgcn_readfirstlane(st);
+    __threadfence();
+    const double factor = (2.38 * 2.38) / (double)d;
+    if (st == L_OK)
+      for (int e = l; e < d * d; e += kWave) S.L_pool[e] = factor * S.L_pool[e];
+  }
+  if (l == 0) *S.pool_valid = st == L_OK ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kThreads) void k_acceptance(ChainState S, int take,
+                                                         double* __restrict__ out) {
+  const int w = wave_in_group(), l = lane_id();
+  const int64_t c = (int64_t)blockIdx.x * kWavesPerGroup + w;
+  if (c >= S.n_chains) return;
+  Ring ring;
+  ring.prob = S.hist_prob + c * S.R;
+  ring.theta = nullptr;
+  ring.mask = S.R - 1;
+  ring.d = S.d;
+  ring.nh = uniform_i64(S.n_hist[c]);
+  ring.length = uniform_i64(S.length[c]);
+  int num, den;
+  ring_acceptance(ring, take, &num, &den);
+  if (l == 0) out[c] = (double)num / (double)den;
+}
+
+}  // namespace mhx
+

@@ -1,0 +1,312 @@
+// mhx_rtc.cpp -- run-time compilation of user-expression models / prior bodies with hiprtc.
+#include "mhx_rtc.hpp"
+
+#include <dlfcn.h>
+
+#include <cctype>
+#include <cstdio>
+#include <cstring>
+#include <set>
+#include <sstream>
+
+#include "mhx_launch.hpp"
+
+// the device sources, embedded at build time (Makefile -> tools/embed_src.py)
+#include "mhx_embedded_src.inc"
+
+namespace mhx {
+
+// ---- hiprtc, loaded lazily so that libmhx.so itself has no link-time dependency on it ------
+namespace {
+typedef struct _hiprtcProgram* hiprtcProgram;
+struct Hiprtc {
+  void* h = nullptr;
+  int (*CreateProgram)(hiprtcProgram*, const char*, const char*, int, const char**, const char**);
+  int (*CompileProgram)(hiprtcProgram, int, const char**);
+  int (*GetProgramLogSize)(hiprtcProgram, size_t*);
+  int (*GetProgramLog)(hiprtcProgram, char*);
+  int (*GetCodeSize)(hiprtcProgram, size_t*);
+  int (*GetCode)(hiprtcProgram, char*);
+  int (*DestroyProgram)(hiprtcProgram*);
+  const char* (*GetErrorString)(int);
+  bool ok = false;
+};
+Hiprtc& rtc() {
+  static Hiprtc r;
+  if (r.h) return r;
+  const char* names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"};
+  for (const char* n : names) {
+    r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (r.h) break;
+  }
+  if (!r.h) return r;
+#define SYM(field, name) *(void**)(&r.field) = dlsym(r.h, name)
+  SYM(CreateProgram, "hiprtcCreateProgram");
+  SYM(CompileProgram, "hiprtcCompileProgram");
+  SYM(GetProgramLogSize, "hiprtcGetProgramLogSize");
+  SYM(GetProgramLog, "hiprtcGetProgramLog");
+  SYM(GetCodeSize, "hiprtcGetCodeSize");
+  SYM(GetCode, "hiprtcGetCode");
+  SYM(DestroyProgram, "hiprtcDestroyProgram");
+  SYM(GetErrorString, "hiprtcGetErrorString");
+#undef SYM
+  r.ok = r.CreateProgram && r.CompileProgram && r.GetProgramLogSize && r.GetProgramLog &&
+         r.GetCodeSize && r.GetCode && r.DestroyProgram;
+  return r;
+}
+}  // namespace
+
+UserProgram::~UserProgram() {
+  if (module) (void)hipModuleUnload(module);
+}
+
+// ---- expression grammar ----------------------------------------------------------------------
+static const char* kFunctions[] = {"exp", "log", "sqrt", "sin", "cos", "tan", "atan", "tanh",
+                                   "abs", "pow", "min",  "max", "floor", nullptr};
+
+int rtc_prepare_expr(const std::string& expr, const std::vector<std::string>& names,
+                     const char* extra, std::string* out, std::string* err) {
+  std::set<std::string> params(names.begin(), names.end());
+  std::set<std::string> funcs;
+  for (int i = 0; kFunctions[i]; ++i) funcs.insert(kFunctions[i]);
+  std::string o;
+  size_t i = 0, n = expr.size();
+  int depth = 0;
+  if (n == 0 || n > 16384) {
+    *err = "expression is empty or longer than 16384 characters";
+    return -1;
+  }
+  while (i < n) {
+    const unsigned char c = (unsigned char)expr[i];
+    if (isspace(c)) {
+      o += ' ';
+      ++i;
+    } else if (isalpha(c) || c == '_') {
+      size_t j = i;
+      while (j < n && (isalnum((unsigned char)expr[j]) || expr[j] == '_')) ++j;
+      const std::string id = expr.substr(i, j - i);
+      if (extra && id == extra) {
+        o += id;
+      } else if (params.count(id)) {
+        o += "p_" + id;
+      } else if (funcs.count(id)) {
+        if (id == "abs") o += "fabs";
+        else if (id == "min") o += "mhx_ux_min";
+        else if (id == "max") o += "mhx_ux_max";
+        else o += id;
+      } else {
+        *err = "unknown identifier '" + id + "' in expression";
+        return -1;
+      }
+      i = j;
+    } else if (isdigit(c) || (c == '.' && i + 1 < n && isdigit((unsigned char)expr[i + 1]))) {
+      size_t j = i;
+      bool is_float = false;
+      while (j < n && isdigit((unsigned char)expr[j])) ++j;
+      if (j < n && expr[j] == '.') {
+        is_float = true;
+        ++j;
+        while (j < n && isdigit((unsigned char)expr[j])) ++j;
+      }
+      if (j < n && (expr[j] == 'e' || expr[j] == 'E')) {
+        size_t k = j + 1;
+        if (k < n && (expr[k] == '+' || expr[k] == '-')) ++k;
+        if (k < n && isdigit((unsigned char)expr[k])) {
+          is_float = true;
+          j = k;
+          while (j < n && isdigit((unsigned char)expr[j])) ++j;
+        }
+      }
+      o += expr.substr(i, j - i);
+      if (!is_float) o += ".0";  // (/ 1 2) must not become an integer division
+      if (j < n && (isalpha((unsigned char)expr[j]) || expr[j] == '_')) {
+        *err = "malformed number in expression";
+        return -1;
+      }
+      i = j;
+    } else if (strchr("+-*/(),?:<>=!&|", c)) {
+      if (c == '(') ++depth;
+      if (c == ')' && --depth < 0) {
+        *err = "unbalanced ')' in expression";
+        return -1;
+      }
+      o += (char)c;
+      ++i;
+    } else {
+      *err = std::string("character '") + (char)c + "' is not allowed in an expression";
+      return -1;
+    }
+  }
+  if (depth != 0) {
+    *err = "unbalanced '(' in expression";
+    return -1;
+  }
+  *out = o;
+  return 0;
+}
+
+// ---- source generation --------------------------------------------------------------------------
+static std::string generate(const std::vector<UserExpr>& models,
+                            const std::vector<UserExpr>& priors) {
+  std::ostringstream s;
+  s << "#include \"mhx_kernels.hpp\"\n"
+       "namespace mhx {\n"
+       "__device__ __forceinline__ double mhx_ux_min(double a, double b) { return a < b ? a : b; }\n"
+       "__device__ __forceinline__ double mhx_ux_max(double a, double b) { return a > b ? a : b; }\n";
+  for (size_t m = 0; m < models.size(); ++m) {
+    const UserExpr& u = models[m];
+    const int np = (int)u.names.size();
+    s << "struct UserModel" << m << " {\n"
+      << "  struct Prep { double p[" << (np > 0 ? np : 1) << "]; };\n"
+      << "  template <class PF>\n"
+      << "  static __device__ __forceinline__ Prep prepare(PF pf, const FnDesc&) {\n"
+      << "    Prep q;\n";
+    for (int j = 0; j < np; ++j) s << "    q.p[" << j << "] = uniform_f64(pf(" << j << "));\n";
+    s << "    return q;\n  }\n"
+      << "  static __device__ __forceinline__ double eval(const Prep& q, double x) {\n";
+    for (int j = 0; j < np; ++j)
+      s << "    const double p_" << u.names[j] << " = q.p[" << j << "]; (void)p_" << u.names[j]
+        << ";\n";
+    s << "    return (double)(" << u.expr << ");\n  }\n};\n";
+  }
+  s << "struct UserSpec {\n"
+       "  template <class PF>\n"
+       "  static __device__ __forceinline__ double loglik(const FnDesc& f, PF pf, bool active,\n"
+       "                                                  GroupLds& lds, double* scratch) {\n"
+       "    switch (f.user_slot) {\n";
+  for (size_t m = 0; m < models.size(); ++m)
+    s << "      case " << m << ": return GenericSpec::by_lik<UserModel" << m
+      << ">(f, pf, active, lds);\n";
+  s << "      default: return GenericSpec::loglik(f, pf, active, lds, scratch);\n"
+       "    }\n  }\n"
+       "  static __device__ __forceinline__ double logprior(const FnDesc& f, const double* th,\n"
+       "                                                    double bounds_total) {\n"
+       "    switch (f.prior_slot) {\n";
+  for (size_t m = 0; m < priors.size(); ++m) {
+    const UserExpr& u = priors[m];
+    s << "      case " << m << ": {\n";
+    for (size_t j = 0; j < u.names.size(); ++j)
+      s << "        const double p_" << u.names[j] << " = th[" << u.index[j] << "]; (void)p_"
+        << u.names[j] << ";\n";
+    s << "        return (double)(" << u.expr << ");\n      }\n";
+  }
+  s << "      default: return bounds_total;\n    }\n  }\n};\n}  // namespace mhx\n"
+       "using namespace mhx;\n"
+       "extern \"C\" __global__ __launch_bounds__(512) void mhx_user_logpost(\n"
+       "    const ProblemDesc* P, const double* theta, int64_t n, double* out, double* parts) {\n"
+       "  k_logpost_body<UserSpec>(P, theta, n, out, parts);\n}\n"
+       "extern \"C\" __global__ __launch_bounds__(512) void mhx_user_init(const ProblemDesc* P,\n"
+       "                                                              ChainState S) {\n"
+       "  k_init_body<UserSpec>(P, S);\n}\n"
+       "extern \"C\" __global__ __launch_bounds__(512) void mhx_user_step(\n"
+       "    const ProblemDesc* P, ChainState S, const double* L, int per_chain_l, const double* z,\n"
+       "    const double* u, const double* T, unsigned char* accepted) {\n"
+       "  k_step_injected_body<UserSpec>(P, S, L, per_chain_l, z, u, T, accepted);\n}\n"
+       "extern \"C\" __global__ __launch_bounds__(512, 4) void mhx_user_adaptive(\n"
+       "    const ProblemDesc* P, ChainState S, RunDesc R, int64_t max_iters, int plain) {\n"
+       "  k_adaptive_body<UserSpec>(P, S, R, max_iters, plain);\n}\n";
+  return s.str();
+}
+
+int rtc_build(const std::vector<UserExpr>& models, const std::vector<UserExpr>& priors, int d,
+              UserProgram* prog, std::string* err) {
+  (void)d;
+  Hiprtc& r = rtc();
+  if (!r.ok) {
+    *err = "libhiprtc.so could not be loaded: expression models need ROCm's hiprtc";
+    return -1;
+  }
+  prog->source = generate(models, priors);
+  const char* hdr_src[] = {kSrc_mhx_kernels_hpp, kSrc_mhx_device_hpp, kSrc_mhx_types_hpp,
+                           kSrc_mhx_h};
+  const char* hdr_name[] = {"mhx_kernels.hpp", "mhx_device.hpp", "mhx_types.hpp",
+                            "../../include/mhx.h"};
+  hiprtcProgram p = nullptr;
+  int rc = r.CreateProgram(&p, prog->source.c_str(), "mhx_user.hip", 4, hdr_src, hdr_name);
+  if (rc != 0) {
+    *err = std::string("hiprtcCreateProgram: ") + (r.GetErrorString ? r.GetErrorString(rc) : "?");
+    return -1;
+  }
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+  rc = r.CompileProgram(p, 4, opts);
+  size_t ls = 0;
+  if (r.GetProgramLogSize(p, &ls) == 0 && ls > 1) {
+    prog->log.resize(ls);
+    r.GetProgramLog(p, &prog->log[0]);
+  }
+  if (rc != 0) {
+    *err = "hiprtc compilation of the expression failed:\n" + prog->log.substr(0, 3000);
+    r.DestroyProgram(&p);
+    return -1;
+  }
+  size_t cs = 0;
+  r.GetCodeSize(p, &cs);
+  std::vector<char> code(cs);
+  r.GetCode(p, code.data());
+  r.DestroyProgram(&p);
+  if (prog->module) {
+    (void)hipModuleUnload(prog->module);
+    prog->module = nullptr;
+  }
+  hipError_t he = hipModuleLoadData(&prog->module, code.data());
+  if (he != hipSuccess) {
+    *err = std::string("hipModuleLoadData: ") + hipGetErrorString(he);
+    return -1;
+  }
+  struct { hipFunction_t* f; const char* n; } fs[] = {{&prog->f_logpost, "mhx_user_logpost"},
+                                                      {&prog->f_init, "mhx_user_init"},
+                                                      {&prog->f_step, "mhx_user_step"},
+                                                      {&prog->f_adaptive, "mhx_user_adaptive"}};
+  for (auto& x : fs) {
+    he = hipModuleGetFunction(x.f, prog->module, x.n);
+    if (he == hipSuccess)
+      he = hipFuncSetAttribute(reinterpret_cast<const void*>(*x.f),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)group_lds_bytes());
+    if (he != hipSuccess) {
+      *err = std::string("module function ") + x.n + ": " + hipGetErrorString(he);
+      return -1;
+    }
+  }
+  return 0;
+}
+
+static inline unsigned grid_for(int64_t n) {
+  return (unsigned)((n + kWavesPerGroup - 1) / kWavesPerGroup);
+}
+
+hipError_t rtc_launch_logpost(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                              const double* theta, int64_t n, double* out, double* parts) {
+  if (n <= 0) return hipSuccess;
+  void* args[] = {(void*)&P, (void*)&theta, (void*)&n, (void*)&out, (void*)&parts};
+  return hipModuleLaunchKernel(p.f_logpost, grid_for(n), 1, 1, kThreads, 1, 1,
+                               (unsigned)group_lds_bytes(), st, args, nullptr);
+}
+hipError_t rtc_launch_init(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                           const ChainState& S) {
+  ChainState s = S;
+  void* args[] = {(void*)&P, (void*)&s};
+  return hipModuleLaunchKernel(p.f_init, grid_for(S.n_chains), 1, 1, kThreads, 1, 1,
+                               (unsigned)group_lds_bytes(), st, args, nullptr);
+}
+hipError_t rtc_launch_step_injected(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                                    const ChainState& S, const double* L, int per_chain_l,
+                                    const double* z, const double* u, const double* T,
+                                    unsigned char* accepted) {
+  ChainState s = S;
+  void* args[] = {(void*)&P, (void*)&s, (void*)&L, (void*)&per_chain_l, (void*)&z,
+                  (void*)&u, (void*)&T, (void*)&accepted};
+  return hipModuleLaunchKernel(p.f_step, grid_for(S.n_chains), 1, 1, kThreads, 1, 1,
+                               (unsigned)group_lds_bytes(), st, args, nullptr);
+}
+hipError_t rtc_launch_adaptive(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                               const ChainState& S, const RunDesc& R, int64_t max_iters,
+                               int plain) {
+  ChainState s = S;
+  RunDesc r = R;
+  void* args[] = {(void*)&P, (void*)&s, (void*)&r, (void*)&max_iters, (void*)&plain};
+  return hipModuleLaunchKernel(p.f_adaptive, grid_for(S.n_chains), 1, 1, kThreads, 1, 1,
+                               (unsigned)group_lds_bytes(), st, args, nullptr);
+}
+
+}  // namespace mhx

@@ -1,0 +1,53 @@
+// mhx_rtc.hpp -- user-expression models and prior bodies: the reference's
+// :function is an arbitrary closure (M:1134-1137) and its priors arbitrary prior-bounds-let
+// bodies (M:346-369, nv-specific.lisp:25-34).  A host shim hands their bodies over as
+// C-syntax expressions; they are spliced into a model / prior struct next to the SAME kernel
+// bodies (mhx_kernels.hpp, embedded in the library) and compiled for gfx950 with hiprtc.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "mhx_types.hpp"
+
+namespace mhx {
+
+constexpr int SPEC_USER = 100;
+
+struct UserExpr {
+  std::string expr;                // validated, identifiers already rewritten
+  std::vector<std::string> names;  // as given by the caller
+  std::vector<int> index;
+};
+
+struct UserProgram {
+  hipModule_t module = nullptr;
+  hipFunction_t f_logpost = nullptr, f_init = nullptr, f_step = nullptr, f_adaptive = nullptr;
+  std::string source, log;
+  ~UserProgram();
+};
+
+// Checks `expr` against the expression grammar of include/mhx.h and rewrites it for splicing:
+// parameter identifiers -> p_<name>, integer literals -> doubles, abs/min/max -> device forms.
+// extra: additional identifiers allowed as they are ("x" or "bounds_total").
+int rtc_prepare_expr(const std::string& expr, const std::vector<std::string>& names,
+                     const char* extra, std::string* out, std::string* err);
+
+// models[slot] / priors[slot] -> compiled module.  Returns 0 or fills *err.
+int rtc_build(const std::vector<UserExpr>& models, const std::vector<UserExpr>& priors, int d,
+              UserProgram* prog, std::string* err);
+
+hipError_t rtc_launch_logpost(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                              const double* theta, int64_t n, double* out, double* parts);
+hipError_t rtc_launch_init(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                           const ChainState& S);
+hipError_t rtc_launch_step_injected(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                                    const ChainState& S, const double* L, int per_chain_l,
+                                    const double* z, const double* u, const double* T,
+                                    unsigned char* accepted);
+hipError_t rtc_launch_adaptive(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                               const ChainState& S, const RunDesc& R, int64_t max_iters,
+                               int plain);
+
+}  // namespace mhx

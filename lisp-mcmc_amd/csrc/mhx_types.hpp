@@ -10,7 +10,9 @@
 //                  is entries n_hist-1, n_hist-2, ...
 //   controller     L[C][d][d] row-major, temperature[C], loop_i[C], flags
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 #include "../../include/mhx.h"
 
@@ -37,6 +39,8 @@ struct FnDesc {
   int64_t n_tiles;  // ceil(n / kTilePoints)
   double lik_const; // normal: sum_i(-1/2 log 2pi - log sigma_i); poisson: -sum_i logfact(k_i)
   double xmin, xmax; // range of x over the n points (fast-path preconditions of the models)
+  int32_t user_slot;  // >= 0: index of the run-time compiled expression model (MHX_MODEL_EXPR)
+  int32_t prior_slot; // >= 0: index of the run-time compiled prior body, else -1
 };
 
 struct ProblemDesc {

@@ -37,6 +37,23 @@ class Engine:
         ix, ixp = capi.as_i32(list(param_index))
         capi.check(capi.lib().mhx_set_function(self._h, k, model, shp, len(shape), ixp, len(ix)))
 
+    @staticmethod
+    def _names(names):
+        arr = (C.c_char_p * max(len(names), 1))(*[n.encode() for n in names])
+        return arr
+
+    def set_function_expr(self, k, expr, names, param_index):
+        """function k as a C-syntax expression over x and `names` (see include/mhx.h)"""
+        ix, ixp = capi.as_i32(list(param_index))
+        capi.check(capi.lib().mhx_set_function_expr(self._h, k, expr.encode(), self._names(names),
+                                                    ixp, len(ix)))
+
+    def set_prior_expr(self, k, expr, names, index):
+        """body of function k's prior over bounds_total and `names` (global parameter indices)"""
+        ix, ixp = capi.as_i32(list(index))
+        capi.check(capi.lib().mhx_set_prior_expr(self._h, k, (expr or "").encode(),
+                                                 self._names(names), ixp, len(ix)))
+
     def set_dataset(self, k, x, y, sigma=None, likelihood=capi.LIK_NORMAL):
         xa, xp = capi.as_f64(x)
         ya, yp = capi.as_f64(y)

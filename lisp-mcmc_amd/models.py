@@ -10,10 +10,27 @@ from . import _capi as capi
 
 
 class Model:
-    def __init__(self, model_id, keys, shape=()):
+    def __init__(self, model_id, keys, shape=(), expr=None):
         self.model_id = int(model_id)
-        self.keys = [str(k).lstrip(":").lower() for k in keys]
+        from .sexpr import mangle
+        self.keys = [mangle(str(k)) for k in keys]
         self.shape = tuple(int(s) for s in shape)
+        self.expr = expr  # C-syntax body for MODEL_EXPR
+
+
+def lisp(lambda_text):
+    """An arbitrary model from the TEXT of the reference-style closure, e.g.
+    lisp('(lambda (x &key m b &allow-other-keys) (+ b (* m x)))').  The body is translated to a
+    C expression (sexpr.py) and compiled for gfx950 at walker-create time (hiprtc)."""
+    from . import sexpr
+    keys, expr = sexpr.lambda_to_expr(lambda_text)
+    return Model(capi.MODEL_EXPR, keys, expr=expr)
+
+
+def expr(c_expression, keys):
+    """An arbitrary model from a C-syntax expression over x and the keys (include/mhx.h)."""
+    from . import sexpr
+    return Model(capi.MODEL_EXPR, [sexpr.mangle(k) for k in keys], expr=c_expression)
 
     def __repr__(self):
         return "Model(%d, %r, %r)" % (self.model_id, self.keys, self.shape)

@@ -1,0 +1,212 @@
+"""Lisp s-expression -> C expression, for model bodies and prior bodies.
+
+The reference's :function is `(lambda (x &key m b &allow-other-keys) (+ b (* m x)))`
+(mcmc-fitting.lisp:1134-1137) and its priors are prior-bounds-let bodies
+(mcmc-fitting.lisp:346-369, nv-specific.lisp:25-34).  This module turns the TEXT of such a
+form into the C-syntax expression `mhx_set_function_expr` / `mhx_set_prior_expr` take, which
+libmhx compiles for gfx950 with hiprtc.  (The Common Lisp shim does the same walk on the form
+itself; here the form arrives as a string because Python has no reader.)
+
+Supported: numbers (1, 2.5, 1d-5, 1e3, 1/2), symbols, + - * / (n-ary, unary - and /), 1+ 1-,
+expt, exp log sqrt sin cos tan atan tanh abs, max min, if, < > <= >= = /= (chains), and or
+not, pi.  Anything else raises SexprError naming the operator.
+"""
+import re
+
+_TOKEN = re.compile(r"""\s*(;[^\n]*|[()']|"(?:\\.|[^"])*"|[^\s()';]+)""")
+
+
+class SexprError(ValueError):
+    pass
+
+
+def parse(text):
+    """text -> nested lists of atoms (strings)"""
+    toks = [t for t in _TOKEN.findall(text) if not t.startswith(";")]
+    pos = 0
+
+    def rd():
+        nonlocal pos
+        if pos >= len(toks):
+            raise SexprError("unexpected end of form")
+        t = toks[pos]
+        pos += 1
+        if t == "(":
+            out = []
+            while True:
+                if pos >= len(toks):
+                    raise SexprError("missing )")
+                if toks[pos] == ")":
+                    pos += 1
+                    return out
+                out.append(rd())
+        if t == ")":
+            raise SexprError("unexpected )")
+        if t == "'":
+            return ["quote", rd()]
+        return t
+    form = rd()
+    if pos != len(toks):
+        raise SexprError("trailing text after the form")
+    return form
+
+
+def mangle(sym):
+    """Lisp symbol / keyword -> C identifier (also the name used for the parameter keys)"""
+    s = sym.lstrip(":").lower()
+    s = re.sub(r"[^a-z0-9_]", "_", s)
+    if not s or s[0].isdigit():
+        s = "k_" + s
+    if s in ("x", "bounds_total"):
+        return s
+    return s
+
+
+_NUM = re.compile(r"^[+-]?(\d+\.?\d*|\.\d+)([edfslEDFSL][+-]?\d+)?$")
+_RAT = re.compile(r"^([+-]?\d+)/(\d+)$")
+
+
+def number(tok):
+    """Lisp numeric token -> C literal text, or None"""
+    m = _RAT.match(tok)
+    if m:
+        return "(%s.0/%s.0)" % (m.group(1), m.group(2))
+    if _NUM.match(tok):
+        t = re.sub(r"[dDfFsSlL]", "e", tok)
+        if "e" in t.lower() and t.lower().endswith("e0"):
+            t = t[:-2]
+        if not any(c in t for c in ".eE"):
+            t += ".0"
+        elif t.endswith("."):
+            t += "0"
+        return t
+    return None
+
+
+_FUN1 = {"exp": "exp", "log": "log", "sqrt": "sqrt", "sin": "sin", "cos": "cos", "tan": "tan",
+         "atan": "atan", "tanh": "tanh", "abs": "abs", "floor": "floor"}
+_CMP = {"<": "<", ">": ">", "<=": "<=", ">=": ">=", "=": "==", "/=": "!="}
+
+
+def to_c(form, rename=None):
+    """nested form -> C expression string; rename maps Lisp symbols to C identifiers"""
+    rename = rename or {}
+
+    def sym(s):
+        k = s.lower()
+        if k in rename:
+            return rename[k]
+        if k == "pi":
+            return "3.14159265358979323846"
+        if k in ("t",):
+            return "1.0"
+        if k in ("nil",):
+            return "0.0"
+        return mangle(s)
+
+    def go(f):
+        if isinstance(f, str):
+            n = number(f)
+            return n if n is not None else sym(f)
+        if not f:
+            raise SexprError("empty form ()")
+        op = f[0].lower() if isinstance(f[0], str) else None
+        a = f[1:]
+        if op in ("+", "*"):
+            if not a:
+                return "0.0" if op == "+" else "1.0"
+            return "(" + (" %s " % op).join(go(v) for v in a) + ")"
+        if op == "-":
+            if len(a) == 1:
+                return "(-" + go(a[0]) + ")"
+            return "(" + " - ".join(go(v) for v in a) + ")"
+        if op == "/":
+            if len(a) == 1:
+                return "(1.0 / " + go(a[0]) + ")"
+            return "(" + " / ".join(go(v) for v in a) + ")"
+        if op == "1+":
+            return "(" + go(a[0]) + " + 1.0)"
+        if op == "1-":
+            return "(" + go(a[0]) + " - 1.0)"
+        if op == "expt":
+            return "pow(" + go(a[0]) + ", " + go(a[1]) + ")"
+        if op in _FUN1 and len(a) == 1:
+            return _FUN1[op] + "(" + go(a[0]) + ")"
+        if op == "log" and len(a) == 2:
+            return "(log(" + go(a[0]) + ") / log(" + go(a[1]) + "))"
+        if op in ("max", "min"):
+            out = go(a[0])
+            for v in a[1:]:
+                out = "%s(%s, %s)" % (op, out, go(v))
+            return out
+        if op == "if":
+            els = go(a[2]) if len(a) > 2 else "0.0"
+            return "((%s) ? %s : %s)" % (cond(a[0]), go(a[1]), els)
+        if op in ("the", "coerce", "float") and len(a) >= 2:
+            return go(a[1] if op == "the" else a[0])
+        raise SexprError("operator %r is not supported in a device expression" % (f[0],))
+
+    def cond(f):
+        if isinstance(f, list) and f and isinstance(f[0], str):
+            op = f[0].lower()
+            a = f[1:]
+            if op in _CMP:
+                vals = [go(v) for v in a]
+                if len(vals) == 1:
+                    return "1"
+                return "(" + " && ".join("(%s %s %s)" % (vals[i], _CMP[op], vals[i + 1])
+                                         for i in range(len(vals) - 1)) + ")"
+            if op == "and":
+                return "(" + " && ".join(cond(v) for v in a) + ")" if a else "1"
+            if op == "or":
+                return "(" + " || ".join(cond(v) for v in a) + ")" if a else "0"
+            if op == "not":
+                return "(!" + cond(a[0]) + ")"
+        return "(" + go(f) + " != 0.0)"
+    return go(form)
+
+
+def lambda_to_expr(text):
+    """'(lambda (x &key m b &allow-other-keys) body)' -> (keys ['m', 'b'], C expression)"""
+    form = parse(text)
+    if isinstance(form, list) and len(form) == 2 and form[0] in ("function", "quote"):
+        form = form[1]
+    if not (isinstance(form, list) and len(form) >= 3 and isinstance(form[0], str)
+            and form[0].lower() == "lambda"):
+        raise SexprError("expected (lambda (x &key ...) body)")
+    ll = form[1]
+    if not ll or not isinstance(ll[0], str):
+        raise SexprError("the lambda list must start with the independent variable")
+    xname = ll[0].lower()
+    keys, in_keys = [], False
+    for item in ll[1:]:
+        name = item[0] if isinstance(item, list) else item     # (bg02 0d0) default forms
+        low = name.lower()
+        if low == "&key":
+            in_keys = True
+        elif low.startswith("&"):
+            in_keys = low == "&key"
+        elif in_keys:
+            keys.append(mangle(name))
+    body = [b for b in form[2:] if not (isinstance(b, list) and b and b[0] == "declare")]
+    if len(body) != 1:
+        raise SexprError("the lambda body must be one expression")
+    return keys, to_c(body[0], {xname: "x"})
+
+
+def prior_body_to_expr(text):
+    """prior-bounds-let body, e.g. '(+ bounds-total (if (> mu1 mu2) -1e9 0e0))'"""
+    return to_c(parse(text), {"bounds-total": "bounds_total"})
+
+
+def symbols_of(form, acc=None):
+    acc = set() if acc is None else acc
+    if isinstance(form, str):
+        if number(form) is None:
+            acc.add(form.lower())
+    else:
+        for i, v in enumerate(form):
+            if i == 0 and isinstance(v, str):
+                continue
+            symbols_of(v, acc)
+    return acc

@@ -40,7 +40,9 @@ _LIKS = {
 
 
 def _key(k):
-    return str(k).lstrip(":").lower()
+    """:much-better-name -> much_better_name (the identifier used on both sides of the ABI)"""
+    from .sexpr import mangle
+    return mangle(str(k))
 
 
 class WalkerStep:
@@ -57,15 +59,18 @@ class WalkerStep:
 class PriorBounds:
     """The value of a prior whose body is `bounds-total` of (prior-bounds-let ((key lo hi) ...))"""
 
-    def __init__(self, bounds):
+    def __init__(self, bounds, body=None):
         self.bounds = [(_key(k), float(lo), float(hi)) for k, (lo, hi) in dict(bounds).items()]
+        self.body = body  # Lisp text of the prior-bounds-let body, None = bounds-total
 
 
-def prior_bounds(bounds):
-    """(prior-bounds-let ((:a lo hi) ...) bounds-total) M:346-369 as a log-prior designator.
+def prior_bounds(bounds, body=None):
+    """(prior-bounds-let ((:a lo hi) ...) BODY) M:346-369 as a log-prior designator.
     -1d10 (exp(1d-5 * distance) - 1) outside (lo, hi), strict at both ends; a key missing from
-    the plist reads as 0d0 (M:353)."""
-    return PriorBounds(bounds)
+    the plist reads as 0d0 (M:353).  BODY is the Lisp text of the form's body and may use
+    bounds-total and the parameter names, e.g. nv-specific.lisp:31-34's
+    '(+ bounds-total (if (> mu1 mu2) -1e9 0e0))'; None means `bounds-total`."""
+    return PriorBounds(bounds, body)
 
 
 log_prior_flat = None  # (log-prior-flat params data) => 0d0, M:340-343
@@ -215,7 +220,10 @@ def walker_create(function=None, data=None, params=None, data_error=None, log_li
         missing = [q for q in f.keys if q not in keys]
         if missing:
             raise KeyError("function %d reads keys %s that :params does not supply" % (k, missing))
-        eng.set_function(k, f.model_id, f.shape, [keys.index(q) for q in f.keys])
+        if f.model_id == capi.MODEL_EXPR:
+            eng.set_function_expr(k, f.expr, f.keys, [keys.index(q) for q in f.keys])
+        else:
+            eng.set_function(k, f.model_id, f.shape, [keys.index(q) for q in f.keys])
         lk = liks[k]
         if isinstance(lk, str):
             lk = lk.lstrip("#':").lower()
@@ -228,6 +236,9 @@ def walker_create(function=None, data=None, params=None, data_error=None, log_li
         elif isinstance(pr, PriorBounds):
             eng.set_bounds(k, [keys.index(q) if q in keys else -1 for q, _, _ in pr.bounds],
                            [lo for _, lo, _ in pr.bounds], [hi for _, _, hi in pr.bounds])
+            if pr.body:
+                from . import sexpr
+                eng.set_prior_expr(k, sexpr.prior_body_to_expr(pr.body), keys, range(len(keys)))
         else:
             raise capi.MhxError(capi.EUNSUPPORTED,
                                 ":log-prior must be None (log-prior-flat) or prior_bounds(...)")
@@ -308,7 +319,7 @@ def _percentile(n, seq):  # nth-percentile M:1493-1504
 def walker_get(walker, get=":steps", take=None, param=None, chain=0):
     """(walker-get walker &key get take param) M:487-543, served from the device trace."""
     e = walker.engine
-    g = _key(get)
+    g = str(get).lstrip(":").lower()
     keys = walker.param_keys
     cap = int(e.state()["length"][chain])
     t = cap if take is None else min(int(take), cap)

@@ -1,0 +1,105 @@
+"""CPU tests of the Lisp-form -> C-expression translation (lisp-mcmc_amd/sexpr.py): the C text
+is compiled with gcc and compared with a test-side evaluation of the original form."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import sexpr_eval
+
+
+@pytest.fixture(scope="module")
+def sx():
+    import lisp_mcmc_amd
+    from lisp_mcmc_amd import sexpr
+    return sexpr
+
+
+def compile_c(exprs, names):
+    """exprs: list of C expressions over x and names -> callable(i, x, p)"""
+    src = ["#include <math.h>",
+           "static double mhx_ux_min(double a,double b){return a<b?a:b;}",
+           "static double mhx_ux_max(double a,double b){return a>b?a:b;}",
+           "#define min mhx_ux_min\n#define max mhx_ux_max\n#define abs fabs"]
+    for i, e in enumerate(exprs):
+        decl = "".join("double %s = p[%d]; (void)%s; " % (n, j, n) for j, n in enumerate(names))
+        src.append("double f%d(double x, const double* p, double bounds_total) { %s return (double)(%s); }"
+                   % (i, decl, e))
+    d = tempfile.mkdtemp()
+    c, so = os.path.join(d, "e.c"), os.path.join(d, "e.so")
+    open(c, "w").write("\n".join(src))
+    subprocess.check_call(["gcc", "-O0", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, c, "-lm"])
+    lib = C.CDLL(so)
+    fns = []
+    for i in range(len(exprs)):
+        f = getattr(lib, "f%d" % i)
+        f.restype = C.c_double
+        f.argtypes = [C.c_double, C.POINTER(C.c_double), C.c_double]
+        fns.append(f)
+    return fns
+
+
+FORMS = [
+    ("(lambda (x &key m b &allow-other-keys) (+ b (* m x)))", ["m", "b"]),
+    ("(lambda (x &key b m c d &allow-other-keys) (+ b (* m x) (* c x x) (* d x x x)))", ["b", "m", "c", "d"]),
+    ("(lambda (x &key m b &allow-other-keys) (+ b (* -3 m) (* (- m (/ b 60)) x)))", ["m", "b"]),
+    ("(lambda (x &key a mu w bg &allow-other-keys) (+ bg (* a (exp (- (expt (/ (- x mu) w) 2))))))",
+     ["a", "mu", "w", "bg"]),
+    ("(lambda (x &key scale linewidth x0 (mix 0.5d0) &allow-other-keys)"
+     " (/ (* scale (+ (* (cos mix) -2 (/ (- x x0) linewidth)) (* (sin mix) (- 1 (expt (/ (- x x0) linewidth) 2)))))"
+     "    (expt (1+ (expt (/ (- x x0) linewidth) 2)) 2)))", ["scale", "linewidth", "x0", "mix"]),
+    ("(lambda (x &key a tau &allow-other-keys) (if (< 0 tau 1d3) (* a (exp (/ (- x) tau))) (max a 1/2 (abs x))))",
+     ["a", "tau"]),
+    ("(lambda (tt &key much-better-param-name1 p2 &allow-other-keys) (* much-better-param-name1 (sqrt (abs (- tt p2))) pi))",
+     ["much_better_param_name1", "p2"]),
+]
+
+
+def test_lambda_translation_matches_lisp_semantics(sx):
+    rng = np.random.default_rng(0)
+    for text, want_keys in FORMS:
+        keys, cexpr = sx.lambda_to_expr(text)
+        assert keys == want_keys, text
+        fn = compile_c([cexpr], keys)[0]
+        form = sx.parse(text)
+        xname = form[1][0].lower()
+        for _ in range(25):
+            p = rng.uniform(0.3, 2.0, len(keys))
+            x = float(rng.uniform(-2, 3))
+            env = {xname: x}
+            lisp_names = [(it[0] if isinstance(it, list) else it).lower() for it in form[1][1:]
+                          if not (it if isinstance(it, str) else it[0]).startswith("&")]
+            env.update(dict(zip(lisp_names, p)))
+            ref = sexpr_eval.evaluate(form[2], env)
+            got = fn(x, p.ctypes.data_as(C.POINTER(C.c_double)), 0.0)
+            assert got == ref or abs(got - ref) <= 4e-16 * abs(ref), (text, x, p, got, ref)
+
+
+def test_prior_body_translation(sx):
+    body = "(+ bounds-total (if (> mu1 mu2) -1e9 0e0) (if (< (- mu2 mu1) 6) -1e9 0e0) (if (not (< 0.9 (/ scale1 scale2) 1.1)) -1e9 0e0))"
+    cexpr = sx.prior_body_to_expr(body)   # nv-specific.lisp:31-34
+    names = ["mu1", "mu2", "scale1", "scale2"]
+    fn = compile_c([cexpr], names)[0]
+    form = sx.parse(body)
+    for mu1, mu2, s1, s2, bt in [(2860, 2880, 1.0, 1.0, 0.0), (2880, 2860, 1.0, 1.0, -5.0),
+                                 (2860, 2863, 1.0, 1.0, 0.0), (2860, 2880, 1.0, 2.0, -1.25)]:
+        p = np.array([mu1, mu2, s1, s2], dtype=float)
+        env = dict(zip(names, p))
+        env["bounds-total"] = bt
+        ref = sexpr_eval.evaluate(form, env)
+        got = fn(0.0, p.ctypes.data_as(C.POINTER(C.c_double)), bt)
+        assert got == ref
+
+
+def test_rejects_unsupported_forms(sx):
+    with pytest.raises(sx.SexprError):
+        sx.lambda_to_expr("(lambda (x &key a) (funcall a x))")
+    with pytest.raises(sx.SexprError):
+        sx.lambda_to_expr("(lambda (x &key a) (let ((b a)) b))")
+    with pytest.raises(sx.SexprError):
+        sx.lambda_to_expr("(defun f (x) x)")
+    assert sx.number("1d-5") == "1e-5" and sx.number("2") == "2.0" and sx.number("1/2") == "(1.0/2.0)"
+    assert sx.mangle(":much-better-param-name1") == "much_better_param_name1"
