@@ -127,7 +127,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import lisp_mcmc_amd as mhx
 
-    spec, chains, b_pt, desc = synth_workload(args.workload)
+    as_expr = args.workload == "c2expr"  # config 2 with the model given as a Lisp closure text
+    spec, chains, b_pt, desc = synth_workload("c2" if as_expr else args.workload)
     if args.chains:
         chains = args.chains
     n_adapt = 30000  # (walker-adaptive-steps w) default n, mcmc-fitting.lisp:946
@@ -135,6 +136,13 @@ def main():
     e = spec.engine(mhx, chains, device=local_rank if world > 1 else 0, seed=0x5EED0003,
                     chain_offset=rank * chains,
                     adapt_mode=mhx.capi.ADAPT_POOLED if pooled else mhx.capi.ADAPT_FAITHFUL)
+    if as_expr:
+        keys, cexpr = mhx.sexpr.lambda_to_expr(
+            "(lambda (x &key b0 b1 a1 mu1 w1 a2 mu2 w2 &allow-other-keys)"
+            " (+ (+ b0 (* b1 x)) (* a1 (exp (- (expt (/ (- x mu1) w1) 2))))"
+            "    (* a2 (exp (- (expt (/ (- x mu2) w2) 2))))))")
+        e.set_function_expr(0, cexpr, keys, list(range(8)))
+        desc += " [model compiled at run time from its Lisp closure text]"
     if pooled and dist is not None:
         # the one exchange step of the path: 1+d+d^2 doubles summed over ranks every 200
         # iterations, RCCL over xGMI directly on the engine's device buffer

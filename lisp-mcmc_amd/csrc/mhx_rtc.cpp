@@ -5,6 +5,7 @@
 
 #include <cctype>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 #include <sstream>
@@ -62,7 +63,7 @@ UserProgram::~UserProgram() {
 
 // ---- expression grammar ----------------------------------------------------------------------
 static const char* kFunctions[] = {"exp", "log", "sqrt", "sin", "cos", "tan", "atan", "tanh",
-                                   "abs", "pow", "min",  "max", "floor", nullptr};
+                                   "abs", "pow", "min",  "max", "floor", "ipow", nullptr};
 
 int rtc_prepare_expr(const std::string& expr, const std::vector<std::string>& names,
                      const char* extra, std::string* out, std::string* err) {
@@ -93,6 +94,7 @@ int rtc_prepare_expr(const std::string& expr, const std::vector<std::string>& na
         if (id == "abs") o += "fabs";
         else if (id == "min") o += "mhx_ux_min";
         else if (id == "max") o += "mhx_ux_max";
+        else if (id == "ipow") o += "mhx_ux_ipow";
         else o += id;
       } else {
         *err = "unknown identifier '" + id + "' in expression";
@@ -152,7 +154,18 @@ static std::string generate(const std::vector<UserExpr>& models,
   s << "#include \"mhx_kernels.hpp\"\n"
        "namespace mhx {\n"
        "__device__ __forceinline__ double mhx_ux_min(double a, double b) { return a < b ? a : b; }\n"
-       "__device__ __forceinline__ double mhx_ux_max(double a, double b) { return a > b ? a : b; }\n";
+       "__device__ __forceinline__ double mhx_ux_max(double a, double b) { return a > b ? a : b; }\n"
+       // (expt base n) with an integer n: SBCL's intexp order of multiplications
+       "__device__ __forceinline__ double mhx_ux_ipow(double base, double pw) {\n"
+       "  int power = (int)pw; const bool neg = power < 0; if (neg) power = -power;\n"
+       "  int nextn = power >> 1; double total = (power & 1) ? base : 1.0;\n"
+       "  while (nextn != 0) { base = base * base; if (nextn & 1) total = base * total; nextn >>= 1; }\n"
+       "  return neg ? 1.0 / total : total;\n}\n";
+  // Divisions by expressions that do not depend on x (1/w, 1/tau ...) are loop invariant; with
+  // reciprocal math the compiler forms the reciprocal once per step instead of dividing per
+  // data point (<= 1 ulp per quotient, inside the stated tolerance).  MHX_EXPR_EXACT_DIV=1
+  // keeps IEEE divisions.
+  const bool recip = !(getenv("MHX_EXPR_EXACT_DIV") && atoi(getenv("MHX_EXPR_EXACT_DIV")) != 0);
   for (size_t m = 0; m < models.size(); ++m) {
     const UserExpr& u = models[m];
     const int np = (int)u.names.size();
@@ -163,7 +176,8 @@ static std::string generate(const std::vector<UserExpr>& models,
       << "    Prep q;\n";
     for (int j = 0; j < np; ++j) s << "    q.p[" << j << "] = uniform_f64(pf(" << j << "));\n";
     s << "    return q;\n  }\n"
-      << "  static __device__ __forceinline__ double eval(const Prep& q, double x) {\n";
+      << "  static __device__ __forceinline__ double eval(const Prep& q, double x) {\n"
+      << (recip ? "#pragma clang fp reciprocal(on)\n" : "");
     for (int j = 0; j < np; ++j)
       s << "    const double p_" << u.names[j] << " = q.p[" << j << "]; (void)p_" << u.names[j]
         << ";\n";
@@ -202,7 +216,7 @@ static std::string generate(const std::vector<UserExpr>& models,
        "    const ProblemDesc* P, ChainState S, const double* L, int per_chain_l, const double* z,\n"
        "    const double* u, const double* T, unsigned char* accepted) {\n"
        "  k_step_injected_body<UserSpec>(P, S, L, per_chain_l, z, u, T, accepted);\n}\n"
-       "extern \"C\" __global__ __launch_bounds__(512, 4) void mhx_user_adaptive(\n"
+       "extern \"C\" __global__ __launch_bounds__(512, 2) void mhx_user_adaptive(\n"
        "    const ProblemDesc* P, ChainState S, RunDesc R, int64_t max_iters, int plain) {\n"
        "  k_adaptive_body<UserSpec>(P, S, R, max_iters, plain);\n}\n";
   return s.str();

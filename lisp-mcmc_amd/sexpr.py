@@ -129,6 +129,10 @@ def to_c(form, rename=None):
         if op == "1-":
             return "(" + go(a[0]) + " - 1.0)"
         if op == "expt":
+            # an INTEGER exponent is repeated multiplication in Common Lisp (exact intexp
+            # order), a float exponent goes through pow like (expt q 2d0) of M:377
+            if isinstance(a[1], str) and re.match(r"^[+-]?\d+$", a[1]) and abs(int(a[1])) <= 64:
+                return "ipow(" + go(a[0]) + ", " + str(int(a[1])) + ")"
             return "pow(" + go(a[0]) + ", " + go(a[1]) + ")"
         if op in _FUN1 and len(a) == 1:
             return _FUN1[op] + "(" + go(a[0]) + ")"

@@ -46,6 +46,16 @@ def evaluate(form, env):
     if op == "1-":
         return ev(a[0]) - 1.0
     if op == "expt":
+        if isinstance(a[1], str) and a[1].lstrip("+-").isdigit():   # SBCL intexp
+            base, power = ev(a[0]), int(a[1])
+            neg, power = power < 0, abs(power)
+            nextn, total = power >> 1, (base if power & 1 else 1.0)
+            while nextn:
+                base = base * base
+                if nextn & 1:
+                    total = base * total
+                nextn >>= 1
+            return 1.0 / total if neg else total
         return math.pow(ev(a[0]), ev(a[1]))
     if op in ("exp", "sqrt", "sin", "cos", "tan", "atan", "tanh", "floor"):
         return float(getattr(math, op)(ev(a[0])))

@@ -23,7 +23,11 @@ def compile_c(exprs, names):
     src = ["#include <math.h>",
            "static double mhx_ux_min(double a,double b){return a<b?a:b;}",
            "static double mhx_ux_max(double a,double b){return a>b?a:b;}",
-           "#define min mhx_ux_min\n#define max mhx_ux_max\n#define abs fabs"]
+           "#define min mhx_ux_min\n#define max mhx_ux_max\n#define abs fabs",
+           # SBCL's intexp (repeated squaring) for (expt base <integer>)
+           "static double ipow(double base, double pw){int power=(int)pw;int neg=power<0;if(neg)power=-power;"
+           "int nextn=power>>1;double total=(power&1)?base:1.0;"
+           "while(nextn){base=base*base;if(nextn&1)total=base*total;nextn>>=1;}return neg?1.0/total:total;}"]
     for i, e in enumerate(exprs):
         decl = "".join("double %s = p[%d]; (void)%s; " % (n, j, n) for j, n in enumerate(names))
         src.append("double f%d(double x, const double* p, double bounds_total) { %s return (double)(%s); }"
