@@ -59,6 +59,12 @@ library, or without a gfx950 device, walker-create signals MHX-ERROR."
   (e :pointer) (k :int) (x :pointer) (y :pointer) (sigma :pointer) (n :size) (likelihood :int))
 (cffi:defcfun ("mhx_set_bounds" %mhx-set-bounds) :int
   (e :pointer) (k :int) (idx :pointer) (lo :pointer) (hi :pointer) (n :int))
+(cffi:defcfun ("mhx_set_function_expr" %mhx-set-function-expr) :int
+  (e :pointer) (k :int) (expr :string) (param-names :pointer) (param-index :pointer) (n-index :int))
+(cffi:defcfun ("mhx_set_prior_expr" %mhx-set-prior-expr) :int
+  (e :pointer) (k :int) (expr :string) (names :pointer) (index :pointer) (n :int))
+(cffi:defcfun ("mhx_get_pooled" %mhx-get-pooled) :int
+  (e :pointer) (stats :pointer) (l-pool :pointer) (valid :pointer) (refreshes :pointer))
 (cffi:defcfun ("mhx_init_chains" %mhx-init-chains) :int
   (e :pointer) (theta0 :pointer) (broadcast :int))
 (cffi:defcfun ("mhx_logpost" %mhx-logpost) :int
@@ -119,6 +125,18 @@ mask the traps around every foreign call (SURVEY 8b)."
   (let ((i 0))
     (map nil (lambda (v) (setf (cffi:mem-aref ptr :int32 i) v) (incf i)) seq)
     ptr))
+
+(defmacro with-c-strings ((var strings) &body body)
+  "VAR: a foreign array of char* holding copies of STRINGS for the extent of BODY"
+  (let ((n (gensym "N")) (ptrs (gensym "PTRS")) (i (gensym "I")))
+    `(let* ((,n (length ,strings))
+            (,ptrs (mapcar #'cffi:foreign-string-alloc ,strings)))
+       (unwind-protect
+            (cffi:with-foreign-object (,var :pointer (max 1 ,n))
+              (loop for p in ,ptrs for ,i from 0
+                    do (setf (cffi:mem-aref ,var :pointer ,i) p))
+              ,@body)
+         (mapc #'cffi:foreign-string-free ,ptrs)))))
 
 (defun read-doubles (ptr n)
   (let ((out (make-array n :element-type 'double-float)))

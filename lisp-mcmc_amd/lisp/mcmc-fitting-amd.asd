@@ -11,4 +11,5 @@
   :components ((:file "package")
                (:file "bindings")
                (:file "models")
+               (:file "expr")
                (:file "walker")))

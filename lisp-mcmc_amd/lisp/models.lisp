@@ -9,7 +9,8 @@
 (defstruct model
   (id 0 :type fixnum)
   (keys nil :type list)
-  (shape nil :type list))
+  (shape nil :type list)
+  (expr nil))                           ; C-syntax body for id 7 (MHX_MODEL_EXPR), see expr.lisp
 
 (defun poly-model (&rest keys)
   "f = c0 + c1 x + ... ; (poly-model :b :m) is (+ b (* m x)), mcmc-fitting.lisp:1186"
@@ -55,7 +56,9 @@
                                                 cross to the GPU; see INTEGRATION.md)" d)))))
 
 ;;; prior designators
-(defstruct prior-bounds-spec (bounds nil :type list))
+(defstruct prior-bounds-spec
+  (bounds nil :type list)
+  (body-expr nil))                      ; C-syntax prior body, nil = bounds-total (expr.lisp)
 
 (defun prior-bounds (&rest key-low-high)
   "(prior-bounds '(:x -10 10) '(:y 100 200)) stands for a prior whose body is the

@@ -23,5 +23,7 @@
    ;; model designators (what replaces a Lisp closure as :function)
    #:model #:make-model #:poly-model #:line-model #:gauss-peaks-model #:lorentz-peaks-model
    #:lorder-mixed-bg-model #:exp-decay-model #:sinusoid-model #:pvoigt2-model
+   ;; arbitrary closures / prior bodies, compiled at run time (expr.lisp)
+   #:expr-model #:prior-bounds-let-amd #:form->c #:bounds-total
    ;; engine-level extras
    #:walker-n-chains #:walker-chain-status #:mhx-error #:mhx-error-code #:mhx-error-message))

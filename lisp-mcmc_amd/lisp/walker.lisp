@@ -134,9 +134,15 @@ set that steps as one batch."
                                              (cshape :int32 (max 1 (length shape))))
                    (fill-int32s cidx idx)
                    (fill-int32s cshape shape)
-                   (with-c-call
-                     (check (%mhx-set-function engine k (model-id fn) cshape (length shape)
-                                               cidx (length idx)))))
+                   (if (model-expr fn)
+                       ;; an arbitrary closure body: compiled for gfx950 at init (expr.lisp)
+                       (with-c-strings (cnames (mapcar #'mangle-symbol (model-keys fn)))
+                         (with-c-call
+                           (check (%mhx-set-function-expr engine k (model-expr fn) cnames cidx
+                                                          (length idx)))))
+                       (with-c-call
+                         (check (%mhx-set-function engine k (model-id fn) cshape (length shape)
+                                                   cidx (length idx))))))
                  (cffi:with-foreign-objects ((cx :double (max 1 n)) (cy :double (max 1 n))
                                              (cs :double (max 1 n)))
                    (fill-doubles cx (first ds))
@@ -157,7 +163,14 @@ set that steps as one batch."
                      (fill-doubles lo (mapcar #'second bounds))
                      (fill-doubles hi (mapcar #'third bounds))
                      (with-c-call
-                       (check (%mhx-set-bounds engine k bi lo hi (length bounds))))))))
+                       (check (%mhx-set-bounds engine k bi lo hi (length bounds)))))
+                   (when (and (prior-bounds-spec-p pri) (prior-bounds-spec-body-expr pri))
+                     (cffi:with-foreign-object (gi :int32 (max 1 d))
+                       (fill-int32s gi (loop for i below d collect i))
+                       (with-c-strings (cnames (mapcar #'mangle-symbol keys))
+                         (with-c-call
+                           (check (%mhx-set-prior-expr engine k (prior-bounds-spec-body-expr pri)
+                                                       cnames gi d)))))))))
       (cffi:with-foreign-object (th :double d)
         (fill-doubles th values)
         (with-c-call (check (%mhx-init-chains engine th 1))))
