@@ -625,6 +625,12 @@ int mhx_set_prior_expr(mhx_engine* e, int k, const char* expr, const char* const
     u.names.push_back(names[j]);
     u.index.push_back(index[j]);
   }
+  // the macro also binds <key>-bound, the penalty of that one key (M:356-360, docstring M:348):
+  // identifier <name>_bound, encoded as index -(g+1)
+  for (int j = 0; j < n; ++j) {
+    u.names.push_back(std::string(names[j]) + "_bound");
+    u.index.push_back(-(index[j] + 1));
+  }
   std::string err;
   if (rtc_prepare_expr(expr, u.names, "bounds_total", &u.expr, &err) != 0)
     return fail(MHX_EINVAL, "%s", err.c_str());

@@ -240,6 +240,14 @@ __device__ __forceinline__ double logprior_fn(const FnDesc& f, const double* the
   return acc;
 }
 
+// the <key>-bound variable of prior-bounds-let (M:356-360) for global parameter g; 0 when the
+// block has no bound on that key
+__device__ __forceinline__ double bound_of(const FnDesc& f, const double* theta, int g) {
+  for (int i = 0; i < f.n_bounds; ++i)
+    if (f.bidx[i] == g) return bound_penalty(theta[g], f.blo[i], f.bhi[i]);
+  return 0.0;
+}
+
 // theta' of this wave is in lds.prop[w]; collective over the workgroup
 template <class Spec>
 __device__ __forceinline__ double group_logpost(const ProblemDesc& P, bool active, GroupLds& lds,

@@ -199,9 +199,14 @@ static std::string generate(const std::vector<UserExpr>& models,
   for (size_t m = 0; m < priors.size(); ++m) {
     const UserExpr& u = priors[m];
     s << "      case " << m << ": {\n";
-    for (size_t j = 0; j < u.names.size(); ++j)
-      s << "        const double p_" << u.names[j] << " = th[" << u.index[j] << "]; (void)p_"
-        << u.names[j] << ";\n";
+    for (size_t j = 0; j < u.names.size(); ++j) {
+      if (u.index[j] >= 0)
+        s << "        const double p_" << u.names[j] << " = th[" << u.index[j] << "];";
+      else  // <key>-bound: the penalty of that key in this function's bounds block
+        s << "        const double p_" << u.names[j] << " = bound_of(f, th, "
+          << (-u.index[j] - 1) << ");";
+      s << " (void)p_" << u.names[j] << ";\n";
+    }
     s << "        return (double)(" << u.expr << ");\n      }\n";
   }
   s << "      default: return bounds_total;\n    }\n  }\n};\n}  // namespace mhx\n"

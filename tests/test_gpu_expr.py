@@ -113,6 +113,29 @@ def test_prior_body_with_cross_parameter_terms(mhx):
     e1.close()
 
 
+def test_prior_body_key_bound_variables(mhx, orc):
+    """the docstring example of prior-bounds-let (mcmc-fitting.lisp:348):
+    (+ bounds-total (* 4 x-bound)) - each key also binds <key>-bound"""
+    s = pb.two_peak(n=100, seed=74)
+    e = build_two_peak(mhx, s, 1, body="(+ bounds-total (* 4 mu1-bound) w2-bound)")
+    idx, lo, hi = s.bounds[0]
+    th = pb.perturbed(s.theta_star, 6, 0.01, seed=7)
+    th[1, 3] = hi[3] + 0.2          # mu1 above its upper bound
+    th[2, 7] = lo[7] - 0.01         # w2 below its lower bound
+    th[3, 0] = hi[0] + 1.0          # b0 out: only bounds-total sees it
+    got, parts = e.logpost(th, parts=True)
+    pen = lambda v, k: orc.lib().orc_bound_penalty(float(v), float(lo[k]), float(hi[k]))  # noqa
+    for i in range(len(th)):
+        total = 0.0
+        for k in range(8):
+            b = pen(th[i, k], k)
+            total = b if k == 0 else total + b
+        want = (total + 4.0 * pen(th[i, 3], 3)) + pen(th[i, 7], 7)
+        assert parts[i, 1] == pytest.approx(want, rel=1e-9, abs=1e-5), i
+    assert parts[0, 1] == 0.0 and (parts[1:4, 1] < 0.0).all()
+    e.close()
+
+
 def test_expression_errors(mhx):
     e = mhx.Engine(1, 2)
     with pytest.raises(mhx.MhxError) as ei:
