@@ -214,6 +214,44 @@ __device__ __forceinline__ double mexp2_negsq_safe(double t) {
   s = s < -1100.0 ? -1100.0 : s;
   return mexp2(s);
 }
+// log(x) for the Poisson term k*log(lambda) (M:383): the fdlibm recipe (x = 2^k (1+f),
+// s = f/(2+f), log(1+f) = f - (f^2/2 - s (f^2/2 + R(s^2)))) with the quotient formed from
+// v_rcp_f64 + two Newton steps instead of an IEEE division.  < 1 ulp on normal positive x.
+// x <= 0, subnormal, inf or NaN -> NaN: a rate outside (0, inf) is where the reference errors
+// (log of a negative number is complex, log 0 traps), and a NaN log-posterior freezes the chain.
+__device__ __forceinline__ double mlog(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+               Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+               Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+               Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  const int hx0 = (int)(b >> 32);
+  const unsigned int lx = (unsigned int)b;
+  int k = (hx0 >> 20) - 1023;
+  int hx = hx0 & 0x000fffff;
+  const int i = (hx + 0x95f64) & 0x100000;
+  hx |= (i ^ 0x3ff00000);
+  k += (i >> 20);
+  const double m = __longlong_as_double((long long)(((unsigned long long)(unsigned int)hx << 32) | lx));
+  const double f = m - 1.0;
+  const double dd = 2.0 + f;
+  double y = __builtin_amdgcn_rcp(dd);
+  y = __builtin_fma(__builtin_fma(-dd, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-dd, y, 1.0), y, y);
+  const double s = f * y;
+  const double dk = (double)k;
+  const double z = s * s;
+  const double w = z * z;
+  const double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
+  const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+  const double R = t2 + t1;
+  const double hfsq = (0.5 * f) * f;
+  const double r = __builtin_fma(dk, ln2_hi, -((hfsq - __builtin_fma(s, hfsq + R, dk * ln2_lo)) - f));
+  // valid iff 2^-1022 <= x < inf: one unsigned compare on the high word (sign bit fails it)
+  const bool ok = (unsigned int)(hx0 - 0x00100000) < (unsigned int)(0x7ff00000 - 0x00100000);
+  return ok ? r : __builtin_nan("");
+}
 constexpr double kLog2e = 1.4426950408889634074;       // log2(e)
 constexpr double kSqrtLog2e = 1.2011224087864497594;   // sqrt(log2(e))
 // exp(s) through mexp2 (relative error ~ 2 ulp * |s|: callers use it on decaying terms)

@@ -81,55 +81,48 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
       const double* tw = lds.tiles[buf][2];
       const double* tc = lds.tiles[buf][3];
       const int64_t gbase = t * kTilePoints;
-      if constexpr (LIK == MHX_LIK_NORMAL) {
-        // software-pipelined: the LDS reads of the next two points are issued before the
-        // ~76 dependent fp64 instructions of the current two, so no wave waits on lgkmcnt
-        double xa = tx[l], xb = tx[l + kWave], ya = ty[l], yb = ty[l + kWave];
-        double wa = tw[l], wb = tw[l + kWave];
+      // Software-pipelined: the LDS reads of the next two points are issued before the dependent
+      // fp64 chain of the current two, so no wave waits on lgkmcnt.
+      double xa = tx[l], xb = tx[l + kWave], ya = ty[l], yb = ty[l + kWave];
+      double wa = 0, wb = 0, ca = 0, cb = 0;
+      if constexpr (NARR > 2) { wa = tw[l]; wb = tw[l + kWave]; }
+      if constexpr (NARR > 3) { ca = tc[l]; cb = tc[l + kWave]; }
 #pragma unroll
-        for (int k = 0; k < kTilePoints / kWave; k += 2) {
-          double xn = 0, xm = 0, yn = 0, ym = 0, wn = 0, wm = 0;
-          if (k + 2 < kTilePoints / kWave) {
-            const int j = (k + 2) * kWave + l;
-            xn = tx[j]; xm = tx[j + kWave];
-            yn = ty[j]; ym = ty[j + kWave];
-            wn = tw[j]; wm = tw[j + kWave];
-          }
-          __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the arithmetic below
-          const double m0 = model_eval<Model, FAST>(prep, xa);
-          const double m1 = model_eval<Model, FAST>(prep, xb);
+      for (int k = 0; k < kTilePoints / kWave; k += 2) {
+        double xn = 0, xm = 0, yn = 0, ym = 0, wn = 0, wm = 0, cn = 0, cm = 0;
+        if (k + 2 < kTilePoints / kWave) {
+          const int j = (k + 2) * kWave + l;
+          xn = tx[j]; xm = tx[j + kWave];
+          yn = ty[j]; ym = ty[j + kWave];
+          if constexpr (NARR > 2) { wn = tw[j]; wm = tw[j + kWave]; }
+          if constexpr (NARR > 3) { cn = tc[j]; cm = tc[j + kWave]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the arithmetic below
+        const double m0 = model_eval<Model, FAST>(prep, xa);
+        const double m1 = model_eval<Model, FAST>(prep, xb);
+        if constexpr (LIK == MHX_LIK_NORMAL) {
+          // the y array holds y/sigma (host, once): r = y/sigma - m/sigma in one fma
           const double r0 = __builtin_fma(-m0, wa, ya), r1 = __builtin_fma(-m1, wb, yb);
           acc0 = __builtin_fma(r0, r0, acc0);
           acc1 = __builtin_fma(r1, r1, acc1);
-          xa = xn; xb = xm; ya = yn; yb = ym; wa = wn; wb = wm;
-        }
-      } else
-#pragma unroll 2
-      for (int k = 0; k < kTilePoints / kWave; k += 2) {
-        const int i0 = k * kWave + l, i1 = i0 + kWave;
-        const double x0 = tx[i0], x1 = tx[i1];
-        const double y0 = ty[i0], y1 = ty[i1];
-        const double m0 = model_eval<Model, FAST>(prep, x0);
-        const double m1 = model_eval<Model, FAST>(prep, x1);
-        if (LIK == MHX_LIK_NORMAL) {
-          // the y array holds y/sigma (host, once): r = y/sigma - m/sigma in one fma
-          const double r0 = __builtin_fma(-m0, tw[i0], y0), r1 = __builtin_fma(-m1, tw[i1], y1);
-          acc0 = __builtin_fma(r0, r0, acc0);
-          acc1 = __builtin_fma(r1, r1, acc1);
-        } else if (LIK == MHX_LIK_NORMAL_CUTOFF) {
-          const double r0 = __builtin_fma(-m0, tw[i0], y0), r1 = __builtin_fma(-m1, tw[i1], y1);
-          const double t0 = __builtin_fma(-0.5 * r0, r0, tc[i0]);
-          const double t1 = __builtin_fma(-0.5 * r1, r1, tc[i1]);
+        } else if constexpr (LIK == MHX_LIK_NORMAL_CUTOFF) {
+          const double r0 = __builtin_fma(-m0, wa, ya), r1 = __builtin_fma(-m1, wb, yb);
+          const double t0 = __builtin_fma(-0.5 * r0, r0, ca);
+          const double t1 = __builtin_fma(-0.5 * r1, r1, cb);
           acc0 = acc0 + (t0 > -5000.0 ? t0 : -5000.0);  // (max -5000d0 term) M:426
           acc1 = acc1 + (t1 > -5000.0 ? t1 : -5000.0);
           // pads carry c = 0, w = 0 -> max(-5000, 0) = 0
         } else {
           // (- (* k (log lambda)) lambda ...) M:383; pads masked (no neutral pad exists)
-          const double t0 = __builtin_fma(y0, log(m0), -m0);
-          const double t1 = __builtin_fma(y1, log(m1), -m1);
+          const double t0 = __builtin_fma(ya, mlog(m0), -m0);
+          const double t1 = __builtin_fma(yb, mlog(m1), -m1);
+          const int i0 = k * kWave + l;
           acc0 = acc0 + ((gbase + i0) < f.n ? t0 : 0.0);
-          acc1 = acc1 + ((gbase + i1) < f.n ? t1 : 0.0);
+          acc1 = acc1 + ((gbase + i0 + kWave) < f.n ? t1 : 0.0);
         }
+        xa = xn; xb = xm; ya = yn; yb = ym;
+        if constexpr (NARR > 2) { wa = wn; wb = wm; }
+        if constexpr (NARR > 3) { ca = cn; cb = cm; }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of tile t+1 has landed
