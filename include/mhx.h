@@ -247,6 +247,18 @@ int mhx_get_trace(mhx_engine* e, int64_t chain, int take, double* prob, double* 
 int mhx_get_proposal_factor(mhx_engine* e, int64_t chain, int take, double* L_out,
                             int* status, int* n_forward);
 
+/* walker-modify's list surgery (M:566-578) for every chain: :burn-walks n drops the n oldest
+ * steps, :keep-walks n keeps the n newest, :reset makes the walk its oldest retained step,
+ * :reset-to-most-likely the most likely step (both also move last-step); n is ignored by the
+ * resets.  (:add-step happens inside walker-take-step on the device; :delete = mhx_destroy.) */
+enum {
+  MHX_MODIFY_BURN_WALKS = 0,
+  MHX_MODIFY_KEEP_WALKS = 1,
+  MHX_MODIFY_RESET = 2,
+  MHX_MODIFY_RESET_TO_MOST_LIKELY = 3
+};
+int mhx_walker_modify(mhx_engine* e, int action, int64_t n);
+
 /* MHX_ADAPT_POOLED read-back: stats [1+d+d*d] = (n, sum delta, sum delta delta^T) pooled over
  * chains (and ranks) at the last 200-iteration tick; L_pool [d][d] = (2.38^2/d) chol(cov);
  * valid = 1 when that factor is in use; refreshes = ticks performed. */

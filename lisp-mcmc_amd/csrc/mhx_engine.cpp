@@ -1000,6 +1000,30 @@ int mhx_get_proposal_factor(mhx_engine* e, int64_t chain, int take, double* L_ou
   return MHX_OK;
 }
 
+int mhx_walker_modify(mhx_engine* e, int action, int64_t n) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  if (!e->chains_ready) return fail(MHX_ESTATE, "mhx_init_chains has not been called");
+  if (action < MHX_MODIFY_BURN_WALKS || action > MHX_MODIFY_RESET_TO_MOST_LIKELY)
+    return fail(MHX_EINVAL, "unknown walker-modify action %d", action);
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  if (action <= MHX_MODIFY_KEEP_WALKS) {
+    // (subseq walk 0 (- length burn-number)) / (subseq walk 0 keep-number), M:566-569: a bounding
+    // index outside the list is an error in the reference; nothing is changed then
+    std::vector<int64_t> len((size_t)e->cfg.n_chains);
+    HIP_TRY(hipMemcpy(len.data(), e->length.p, len.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    for (int64_t v : len)
+      if (n < 0 || n > v)
+        return fail(MHX_EINVAL, "%s %lld is outside a walk of length %lld",
+                    action == MHX_MODIFY_BURN_WALKS ? ":burn-number" : ":keep-number",
+                    (long long)n, (long long)v);
+  }
+  HIP_TRY(launch_modify(e->stream, e->S, action, n));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->launches++;
+  return MHX_OK;
+}
+
 int mhx_get_pooled(mhx_engine* e, double* stats, double* L_pool, int32_t* valid,
                    uint64_t* refreshes) {
   if (!e) return fail(MHX_EINVAL, "engine is NULL");

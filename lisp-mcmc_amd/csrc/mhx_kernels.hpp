@@ -896,6 +896,44 @@ __global__ __launch_bounds__(kWave) void k_l_matrix(ChainState S, int64_t c, int
   }
 }
 
+// walker-modify's list surgery on the ring (M:566-578).  action 0 :burn-walks n (drop the n
+// oldest steps), 1 :keep-walks n (keep the n newest), 2 :reset (walk <- its OLDEST step:
+// (last (walker-walk w)) of a newest-first list), 3 :reset-to-most-likely.  2 and 3 also move
+// last-step, as the reference does; age and most-likely-step stay.
+__global__ __launch_bounds__(kThreads) void k_modify(ChainState S, int action, int64_t n) {
+  const int w = wave_in_group(), l = lane_id(), d = S.d;
+  const int64_t c = (int64_t)blockIdx.x * kWavesPerGroup + w;
+  if (c >= S.n_chains) return;
+  const int64_t nh = uniform_i64(S.n_hist[c]), len = uniform_i64(S.length[c]);
+  if (action == 0) {
+    if (l == 0) S.length[c] = len - n;
+  } else if (action == 1) {
+    if (l == 0) S.length[c] = n;
+  } else {
+    double th = 0.0, pr = 0.0;
+    if (action == 2) {
+      const int64_t vis = len < (int64_t)S.R ? len : (int64_t)S.R;  // what the ring still holds
+      const int64_t slot = (nh - vis) & (int64_t)(S.R - 1);
+      if (l < d) th = S.hist_theta[(c * S.R + slot) * d + l];
+      pr = S.hist_prob[c * S.R + slot];
+    } else {
+      if (l < d) th = S.best_theta[c * d + l];
+      pr = S.best_prob[c];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (l < d) {
+      S.hist_theta[(c * S.R + 0) * d + l] = th;
+      S.theta[c * d + l] = th;
+    }
+    if (l == 0) {
+      S.hist_prob[c * S.R + 0] = pr;
+      S.prob[c] = pr;
+      S.n_hist[c] = 1;
+      S.length[c] = 1;
+    }
+  }
+}
+
 // ---- pooled adaptive covariance (extension of the north star; not in the reference) --------
 // Step 1: every chain reduces the displacements between its successive forward steps (the
 // vectors lplist-covariance would see, M:543) to (n, sum delta, sum delta delta^T).

@@ -44,5 +44,6 @@ hipError_t launch_acceptance(hipStream_t st, const ChainState& S, int take, doub
 hipError_t launch_pool_stats(hipStream_t st, const ChainState& S, const RunDesc& R);
 hipError_t launch_pool_reduce(hipStream_t st, const ChainState& S);
 hipError_t launch_pool_factor(hipStream_t st, const ChainState& S);
+hipError_t launch_modify(hipStream_t st, const ChainState& S, int action, int64_t n);
 
 }  // namespace mhx

@@ -213,6 +213,12 @@ class Engine:
                                                       C.byref(nf)))
         return st.value, L, nf.value
 
+    MODIFY = {"burn-walks": 0, "keep-walks": 1, "reset": 2, "reset-to-most-likely": 3}
+
+    def modify(self, action, n=0):
+        """walker-modify's :burn-walks / :keep-walks / :reset / :reset-to-most-likely (M:566-578)"""
+        capi.check(capi.lib().mhx_walker_modify(self._h, self.MODIFY[action], int(n)))
+
     def pooled(self):
         d = self.d
         stats, L = np.zeros(1 + d + d * d), np.zeros((d, d))

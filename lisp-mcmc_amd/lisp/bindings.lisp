@@ -63,6 +63,7 @@ library, or without a gfx950 device, walker-create signals MHX-ERROR."
   (e :pointer) (k :int) (expr :string) (param-names :pointer) (param-index :pointer) (n-index :int))
 (cffi:defcfun ("mhx_set_prior_expr" %mhx-set-prior-expr) :int
   (e :pointer) (k :int) (expr :string) (names :pointer) (index :pointer) (n :int))
+(cffi:defcfun ("mhx_walker_modify" %mhx-walker-modify) :int (e :pointer) (action :int) (n :int64))
 (cffi:defcfun ("mhx_get_pooled" %mhx-get-pooled) :int
   (e :pointer) (stats :pointer) (l-pool :pointer) (valid :pointer) (refreshes :pointer))
 (cffi:defcfun ("mhx_init_chains" %mhx-init-chains) :int

@@ -247,6 +247,17 @@ set that steps as one batch."
 (defun walker-walk (walker &optional (chain 0))
   (%trace walker chain (walker-length walker chain)))
 
+(defun walker-modify (walker &key modify burn-number keep-number &allow-other-keys)
+  "M:547-580.  :add-step happens on the device inside walker-take-step; :add-walks is unused
+by the reference itself (M:556 discards the nconc)."
+  (let ((e (engine-of walker)))
+    (ecase modify
+      (:burn-walks (with-c-call (check (%mhx-walker-modify e 0 burn-number))))
+      (:keep-walks (with-c-call (check (%mhx-walker-modify e 1 keep-number))))
+      (:reset (with-c-call (check (%mhx-walker-modify e 2 0))) walker)
+      (:reset-to-most-likely (with-c-call (check (%mhx-walker-modify e 3 0))) walker)
+      (:delete (walker-destroy walker)))))
+
 ;;; ------------------------------------------------------------------ stepping
 (defun walker-adaptive-steps-full (walker &key (n 100000) (temperature 1d3)
                                             (auto :prob-settle)

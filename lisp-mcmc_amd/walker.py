@@ -374,5 +374,17 @@ def walker_modify(walker, modify=None, **kw):
     """(walker-modify ...) M:547-580: only :add-step is on the accelerated path and it is
     performed by the device inside walker-take-step; the list-surgery actions are host-side
     post-processing the engine does not take over yet."""
-    raise capi.MhxError(capi.EUNSUPPORTED,
-                        "walker-modify %s is not part of the accelerated path" % (modify,))
+    m = str(modify).lstrip(":").lower()
+    if m == "burn-walks":
+        walker.engine.modify(m, kw["burn_number"])
+    elif m == "keep-walks":
+        walker.engine.modify(m, kw["keep_number"])
+    elif m in ("reset", "reset-to-most-likely"):
+        walker.engine.modify(m)
+        return walker
+    elif m == "delete":
+        walker.engine.close()
+    else:  # :add-step happens on the device inside walker-take-step; :add-walks is unused (M:556)
+        raise capi.MhxError(capi.EUNSUPPORTED,
+                            "walker-modify %s is not part of the accelerated path" % (modify,))
+    return None

@@ -609,6 +609,35 @@ static void add_step(orc_walker* w, double prob, const double* theta) {
   }
 }
 
+/* walker-modify M:566-578: 0 :burn-walks n, 1 :keep-walks n, 2 :reset, 3 :reset-to-most-likely.
+ * Returns -1 where subseq would signal (bounding index outside the walk). */
+int orc_walker_modify(orc_walker* w, int action, int64_t n) {
+  size_t d = (size_t)w->d;
+  if (action == 0) { /* (subseq walk 0 (- length burn-number)): the NEWEST length-n steps stay */
+    if (n < 0 || n > w->length) return -1;
+    w->length -= n;
+  } else if (action == 1) { /* (subseq walk 0 keep-number) */
+    if (n < 0 || n > w->length) return -1;
+    w->length = n;
+  } else if (action == 2 || action == 3) {
+    double pr, th[MHX_MAX_PARAMS];
+    if (action == 2) { /* (last (walker-walk w)): the OLDEST step of a newest-first list */
+      size_t src = w->n_hist - (size_t)w->length;
+      pr = w->prob[src];
+      memcpy(th, w->theta + src * d, sizeof(double) * d);
+    } else { /* (list (walker-most-likely-step w)) */
+      pr = w->best_prob;
+      memcpy(th, w->best_theta, sizeof(double) * d);
+    }
+    w->n_hist = 0;
+    hist_push(w, pr, th); /* last-step <- (car walk) */
+    w->length = 1;
+  } else {
+    return -1;
+  }
+  return 0;
+}
+
 /* M:1072-1095 */
 int orc_walker_take_step_injected(orc_walker* w, const double* L, const double* z, double u,
                                   double T) {

@@ -90,6 +90,8 @@ void orc_walker_destroy(orc_walker* w);
  * 0 rejected, -1 the reference would have trapped (walker unchanged) */
 int orc_walker_take_step_injected(orc_walker* w, const double* L, const double* z, double u,
                                   double T);
+/* walker-modify M:566-578: 0 :burn-walks n, 1 :keep-walks n, 2 :reset, 3 :reset-to-most-likely */
+int orc_walker_modify(orc_walker* w, int action, int64_t n);
 int64_t orc_walker_length(const orc_walker* w);
 int64_t orc_walker_age(const orc_walker* w);
 void orc_walker_last(const orc_walker* w, double* theta, double* prob);

@@ -71,6 +71,7 @@ def lib():
         "orc_walker_create": (vp, [vp, f64p]),
         "orc_walker_destroy": (None, [vp]),
         "orc_walker_take_step_injected": (i, [vp, f64p, f64p, d, d]),
+        "orc_walker_modify": (i, [vp, i, C.c_int64]),
         "orc_walker_length": (C.c_int64, [vp]),
         "orc_walker_age": (C.c_int64, [vp]),
         "orc_walker_last": (None, [vp, f64p, f64p]),
@@ -177,6 +178,11 @@ class Walker:
         La, Lp = _f64(L)
         za, zp = _f64(z)
         return lib().orc_walker_take_step_injected(self.h, Lp, zp, float(u), float(T))
+
+    MODIFY = {"burn-walks": 0, "keep-walks": 1, "reset": 2, "reset-to-most-likely": 3}
+
+    def modify(self, action, n=0):
+        return lib().orc_walker_modify(self.h, self.MODIFY[action], int(n))
 
     @property
     def length(self):

@@ -238,6 +238,64 @@ def test_philox_stream_and_many_steps(mhx, orc):
     e.close()
 
 
+def test_walker_modify_actions(mhx, orc):
+    """:burn-walks / :keep-walks / :reset / :reset-to-most-likely (M:566-578) on the device ring,
+    interleaved with stepping, against the oracle's list surgery"""
+    s = pb.two_peak(n=300, seed=33)
+    C_ = 5
+    e = s.engine(mhx, C_, seed=77)
+    op = s.oracle(orc)
+    th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=3)
+    e.init_chains(th0)
+    ws = [orc.Walker(op, th0[c]) for c in range(C_)]
+    L = np.diag(0.01 * np.abs(s.theta_star))
+
+    def step(n):
+        e.many_steps(n, L)
+        for c, w in enumerate(ws):
+            w.many_steps(n, L, seed=77, chain_id=c)
+
+    def same():
+        st = e.state()
+        for c, w in enumerate(ws):
+            th, pr = w.last()
+            assert np.array_equal(st["theta"][c], th) and st["length"][c] == w.length
+            assert st["age"][c] == w.age
+            n1, d1 = w.acceptance(1000)
+            assert e.acceptance(1000)[c] == n1 / d1
+            assert e.proposal_factor(c, 500)[0] == w.l_matrix(500)[0]
+            pg, tg = e.trace(c, 40)
+            po, to = w.trace(40)
+            assert np.array_equal(tg, to) and len(pg) == len(po)
+
+    step(300)
+    same()
+    for action, n in (("burn-walks", 100), ("keep-walks", 50)):
+        e.modify(action, n)
+        assert all(w.modify(action, n) == 0 for w in ws)
+        same()
+        step(30)
+        same()
+    with pytest.raises(mhx.MhxError):
+        e.modify("keep-walks", 10 ** 6)      # (subseq walk 0 keep-number) beyond the walk
+    assert ws[0].modify("keep-walks", 10 ** 6) == -1
+    e.modify("reset")
+    for w in ws:
+        w.modify("reset")
+    same()
+    assert (e.state()["length"] == 1).all()
+    step(60)
+    same()
+    e.modify("reset-to-most-likely")
+    for w in ws:
+        w.modify("reset-to-most-likely")
+    st = e.state()
+    assert np.array_equal(st["theta"], st["best_theta"]) and np.array_equal(st["logpost"], st["best_logpost"])
+    step(40)
+    same()
+    e.close()
+
+
 def compare_adaptive(mhx, orc, spec, C, n, seed, auto=1, temperature=10.0, checkpoints=(),
                      l_matrix=None, max_walker_length=0, history_capacity=0):
     e = spec.engine(mhx, C, seed=seed, history_capacity=history_capacity)
