@@ -49,7 +49,9 @@ extern "C" {
 #define MHX_VERSION 100 /* 0.1.0 */
 
 /* ---- limits ------------------------------------------------------------ */
-#define MHX_MAX_PARAMS 64    /* d: length of the shared parameter vector            */
+#define MHX_MAX_PARAMS 63    /* d: length of the shared parameter vector (one lane of the
+                                chain's wavefront per parameter, lane 63 draws the accept
+                                uniform)                                              */
 #define MHX_MAX_FUNCTIONS 16 /* K: functions / datasets of one (global) fit         */
 #define MHX_MAX_FN_PARAMS 32 /* parameters one function gathers from the vector      */
 #define MHX_MAX_BOUNDS 64    /* bounds in one prior-bounds-let block                */
@@ -246,6 +248,11 @@ int mhx_get_trace(mhx_engine* e, int64_t chain, int take, double* prob, double* 
  * M:891-894), 2 uncaught invalid-operation.  n_forward = (length :forward-steps). */
 int mhx_get_proposal_factor(mhx_engine* e, int64_t chain, int take, double* L_out,
                             int* status, int* n_forward);
+
+/* Restore a saved walk (walker-load, sketched in the comments M:987-1001): prob[n], theta[n][d]
+ * NEWEST FIRST, as walker-save would have written them.  Sets the ring (newest
+ * min(n, history_capacity) steps), last-step, length, age = n and the most-likely step. */
+int mhx_set_history(mhx_engine* e, int64_t chain, const double* prob, const double* theta, int n);
 
 /* walker-modify's list surgery (M:566-578) for every chain: :burn-walks n drops the n oldest
  * steps, :keep-walks n keeps the n newest, :reset makes the walk its oldest retained step,

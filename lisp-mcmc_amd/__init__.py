@@ -15,6 +15,9 @@ from .engine import Engine  # noqa: F401
 from . import models  # noqa: F401
 from . import sexpr  # noqa: F401
 from . import distributed  # noqa: F401
+from . import ingest  # noqa: F401
+from .ingest import read_file_to_data, create_walker_data  # noqa: F401
+from .saveload import walker_save, walker_load  # noqa: F401
 from .walker import (  # noqa: F401
     Walker, WalkerStep, walker_create, mcmc_fit, walker_adaptive_steps,
     walker_adaptive_steps_full, walker_many_steps, walker_take_step, walker_get,

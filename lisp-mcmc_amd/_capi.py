@@ -74,6 +74,7 @@ SIGNATURES = {
     "mhx_get_trace": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, f64p, f64p, C.POINTER(C.c_int)]),
     "mhx_get_proposal_factor": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, f64p,
                                           C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mhx_set_history": (C.c_int, [C.c_void_p, C.c_int64, f64p, f64p, C.c_int]),
     "mhx_walker_modify": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
     "mhx_get_pooled": (C.c_int, [C.c_void_p, f64p, f64p, i32p, u64p]),
     "mhx_get_counters": (C.c_int, [C.c_void_p, u64p, u64p]),

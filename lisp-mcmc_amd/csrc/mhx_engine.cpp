@@ -1000,6 +1000,42 @@ int mhx_get_proposal_factor(mhx_engine* e, int64_t chain, int take, double* L_ou
   return MHX_OK;
 }
 
+int mhx_set_history(mhx_engine* e, int64_t chain, const double* prob, const double* theta, int n) {
+  if (!e || !prob || !theta) return fail(MHX_EINVAL, "NULL argument");
+  if (!e->chains_ready) return fail(MHX_ESTATE, "mhx_init_chains has not been called");
+  if (chain < 0 || chain >= e->cfg.n_chains) return fail(MHX_EINVAL, "chain out of range");
+  if (n < 1) return fail(MHX_EINVAL, "a walk has at least one step");
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  const int Rcap = e->S.R, d = e->P.d;
+  const int keep = std::min(n, Rcap);  // the ring holds the newest `keep` steps
+  std::vector<double> hp((size_t)Rcap, 0.0), ht((size_t)Rcap * d, 0.0);
+  // chronological order: step s (0 = newest) of the input is entry keep-1-s of the ring
+  for (int s = 0; s < keep; ++s) {
+    const int slot = keep - 1 - s;
+    hp[(size_t)slot] = prob[s];
+    memcpy(&ht[(size_t)slot * d], theta + (size_t)s * d, sizeof(double) * d);
+  }
+  // most-likely-step as :add-step would have left it (strictly greater wins, oldest first)
+  int best = n - 1;
+  for (int s = n - 2; s >= 0; --s)
+    if (prob[s] > prob[best]) best = s;
+  const int64_t nh = keep, len = keep, age = n;
+  HIP_TRY(hipMemcpy(e->hist_prob.p + chain * Rcap, hp.data(), hp.size() * sizeof(double),
+                    hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->hist_theta.p + chain * Rcap * d, ht.data(), ht.size() * sizeof(double),
+                    hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->n_hist.p + chain, &nh, sizeof nh, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->length.p + chain, &len, sizeof len, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->age.p + chain, &age, sizeof age, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->theta.p + chain * d, theta, sizeof(double) * d, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->prob.p + chain, prob, sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->best_theta.p + chain * d, theta + (size_t)best * d, sizeof(double) * d,
+                    hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->best_prob.p + chain, prob + best, sizeof(double), hipMemcpyHostToDevice));
+  return MHX_OK;
+}
+
 int mhx_walker_modify(mhx_engine* e, int action, int64_t n) {
   if (!e) return fail(MHX_EINVAL, "engine is NULL");
   if (!e->chains_ready) return fail(MHX_ESTATE, "mhx_init_chains has not been called");

@@ -213,6 +213,12 @@ class Engine:
                                                       C.byref(nf)))
         return st.value, L, nf.value
 
+    def set_history(self, chain, prob, theta):
+        """restore a walk, newest first (walker-load)"""
+        pa, pp = capi.as_f64(prob)
+        ta, tp = capi.as_f64(np.asarray(theta, dtype=np.float64).reshape(len(pa), self.d))
+        capi.check(capi.lib().mhx_set_history(self._h, int(chain), pp, tp, len(pa)))
+
     MODIFY = {"burn-walks": 0, "keep-walks": 1, "reset": 2, "reset-to-most-likely": 3}
 
     def modify(self, action, n=0):
