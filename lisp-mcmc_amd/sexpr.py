@@ -146,6 +146,14 @@ def to_c(form, rename=None):
         if op == "if":
             els = go(a[2]) if len(a) > 2 else "0.0"
             return "((%s) ? %s : %s)" % (cond(a[0]), go(a[1]), els)
+        if op in ("elt", "aref", "nth", "svref") and len(a) >= 2:
+            # :single-item parameter styles (M:7-14, M:1189-1195): (elt params 1),
+            # (aref params 1 0), (nth 1 params) name element 1 of the list/vector/column held
+            # under the one key `params`; the host expands such a key into params_0, params_1...
+            seq, ix = (a[1], a[0]) if op == "nth" else (a[0], a[1])
+            if isinstance(seq, str) and isinstance(ix, str) and ix.isdigit():
+                return sym(seq) + "_" + ix
+            raise SexprError("%s needs a literal index into a parameter sequence" % op)
         if op in ("the", "coerce", "float") and len(a) >= 2:
             return go(a[1] if op == "the" else a[0])
         raise SexprError("operator %r is not supported in a device expression" % (f[0],))
@@ -195,7 +203,16 @@ def lambda_to_expr(text):
     body = [b for b in form[2:] if not (isinstance(b, list) and b and b[0] == "declare")]
     if len(body) != 1:
         raise SexprError("the lambda body must be one expression")
-    return keys, to_c(body[0], {xname: "x"})
+    cexpr = to_c(body[0], {xname: "x"})
+    # a key used only through (elt key i) stands for the elements key_0 ... key_n
+    out = []
+    for k in keys:
+        elems = sorted({int(m) for m in re.findall(r"\b%s_(\d+)\b" % re.escape(k), cexpr)})
+        if elems and not re.search(r"\b%s\b" % re.escape(k), cexpr):
+            out += ["%s_%d" % (k, i) for i in range(elems[-1] + 1)]
+        else:
+            out.append(k)
+    return out, cexpr
 
 
 def prior_body_to_expr(text):

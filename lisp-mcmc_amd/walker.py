@@ -136,9 +136,13 @@ def _plist(params):
         if k in keys:
             continue  # first value wins, like getf (M:195-198)
         if not isinstance(v, (int, float, np.floating, np.integer)):
-            raise capi.MhxError(capi.EUNSUPPORTED,
-                                ":single-item parameter styles (M:1153-1155) are host-side "
-                                "marshalling; pass one key per number")
+            # :single-item styles (M:7-14, M:1153-1155): one key holding a list / vector /
+            # d x 1 array; expanded to key_0, key_1, ... (what (elt key i) translates to)
+            flat = np.asarray(v, dtype=np.float64).reshape(-1)
+            for i, vi in enumerate(flat):
+                keys.append("%s_%d" % (k, i))
+                vals.append(float(vi))
+            continue
         keys.append(k)
         vals.append(float(v))
     return keys, np.asarray(vals, dtype=np.float64)

@@ -38,6 +38,21 @@ def test_line_fit_from_lisp_text(mhx, golden):
     assert abs(ml["b"] - bm[0]) < 0.2 and abs(ml["m"] - bm[1]) < 0.05
 
 
+def test_single_item_parameter_styles(mhx, golden):
+    """mcmc-fitting.lisp:1189-1195: one key holding a list / vector / d x 1 array, read with elt /
+    aref inside the closure"""
+    lf = golden["line_fit"]
+    ref = golden["line_fit_initial_logpost_sigma_single"]
+    for text, value in (
+            ("(lambda (x &key params &allow-other-keys) (+ (elt params 0) (* (elt params 1) x)))", [-1, 2]),
+            ("(lambda (x &key params &allow-other-keys) (+ (aref params 0 0) (* (aref params 1 0) x)))",
+             np.array([[-1.0], [2.0]]))):
+        w = mhx.walker_create(function=mhx.models.lisp(text), data=[lf["x"], lf["y"]],
+                              params=[":params", value], data_error=ref["sigma"])
+        assert w.param_keys == ["params_0", "params_1"]
+        assert w.last_step().prob == pytest.approx(ref["value"], rel=1e-14)
+
+
 def build_two_peak(mhx, s, C_, body=None, seed=0):
     keys, cexpr = __import__("lisp_mcmc_amd").sexpr.lambda_to_expr(TWO_PEAK)
     e = mhx.Engine(C_, 8, 1, seed=seed)
