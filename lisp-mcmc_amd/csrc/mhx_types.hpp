@@ -19,9 +19,13 @@
 namespace mhx {
 
 constexpr int kWave = 64;
-constexpr int kWavesPerGroup = 8;           // one wave = one chain; a workgroup shares LDS tiles
+#ifndef MHX_WPG
+#define MHX_WPG 8  // tuning knob (4 / 8 / 16 measured in round 1)
+#endif
+constexpr int kWavesPerGroup = MHX_WPG;     // one wave = one chain; a workgroup shares LDS tiles
 constexpr int kThreads = kWave * kWavesPerGroup;
-constexpr int kTilePoints = 1024;           // data points per LDS tile (per array)
+constexpr int kTilePoints = 2 * kThreads;   // data points per LDS tile (per array): one 16-B
+                                            // LDS-DMA element per thread
 constexpr int kMaxArrays = 4;               // x, y, w, c
 
 struct FnDesc {
