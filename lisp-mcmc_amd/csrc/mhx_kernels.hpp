@@ -87,8 +87,12 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
       double wa = 0, wb = 0, ca = 0, cb = 0;
       if constexpr (NARR > 2) { wa = tw[l]; wb = tw[l + kWave]; }
       if constexpr (NARR > 3) { ca = tc[l]; cb = tc[l + kWave]; }
+      // points of this tile that are data (the rest are neutral pads): short datasets such as
+      // test.lisp's 334 points leave most of their only tile unused
+      const int nv = (int)((f.n - gbase) < (int64_t)kTilePoints ? (f.n - gbase) : (int64_t)kTilePoints);
 #pragma unroll
       for (int k = 0; k < kTilePoints / kWave; k += 2) {
+        if (k * kWave >= nv) break;  // uniform: one scalar compare per two points
         double xn = 0, xm = 0, yn = 0, ym = 0, wn = 0, wm = 0, cn = 0, cm = 0;
         if (k + 2 < kTilePoints / kWave) {
           const int j = (k + 2) * kWave + l;
