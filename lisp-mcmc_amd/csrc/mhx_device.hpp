@@ -252,6 +252,32 @@ __device__ __forceinline__ double mlog(double x) {
   const bool ok = (unsigned int)(hx0 - 0x00100000) < (unsigned int)(0x7ff00000 - 0x00100000);
   return ok ? r : __builtin_nan("");
 }
+// e^x in pure IEEE operations (fma, add, ldexp), so that the oracle's mirror mode reproduces it
+// bit for bit: k = rint(x log2 e), r = x - k ln2 (hi/lo), degree-13 Taylor in Horner form.
+// < 1 ulp for |x| < 700.  Used by the bounds prior (M:360), off the hot loop.
+__device__ __forceinline__ double dexp(double x) {
+  const double MAGIC = 0x1.8p52;
+  const double kd = __builtin_fma(x, 1.4426950408889634074, MAGIC);
+  const double kf = kd - MAGIC;
+  double r = __builtin_fma(-kf, 6.93147180369123816490e-01, x);
+  r = __builtin_fma(-kf, 1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = __builtin_fma(p, r, 1.0 / 479001600.0);
+  p = __builtin_fma(p, r, 1.0 / 39916800.0);
+  p = __builtin_fma(p, r, 1.0 / 3628800.0);
+  p = __builtin_fma(p, r, 1.0 / 362880.0);
+  p = __builtin_fma(p, r, 1.0 / 40320.0);
+  p = __builtin_fma(p, r, 1.0 / 5040.0);
+  p = __builtin_fma(p, r, 1.0 / 720.0);
+  p = __builtin_fma(p, r, 1.0 / 120.0);
+  p = __builtin_fma(p, r, 1.0 / 24.0);
+  p = __builtin_fma(p, r, 1.0 / 6.0);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return ldexp(p, (int)kf);
+}
+
 // 1/d from v_rcp_f64 and two Newton steps (<= 1 ulp; inf/NaN/0 behave like a division):
 // 5 instructions instead of the ~25 of an IEEE fp64 division.  Used for the Lorentzian
 // 1/(1+u^2), whose denominator is >= 1.

@@ -224,7 +224,7 @@ __device__ __forceinline__ double bound_penalty(double p, double lo, double hi) 
   if (lo < p && p < hi) return 0.0;
   const double a = fabs(p - hi), b = fabs(p - lo);
   const double m = a < b ? a : b;
-  return -1e10 * (exp(m * 1e-5) - 1.0);
+  return -1e10 * (dexp(m * 1e-5) - 1.0);
 }
 __device__ __forceinline__ double logprior_fn(const FnDesc& f, const double* theta) {
   double acc = 0.0;
@@ -657,7 +657,7 @@ __device__ __forceinline__ void k_step_injected_body(
   } else {
     const double uu = uniform_f64(u[c]), TT = uniform_f64(T[c]);
     // here the caller's u stands for (random 1.0d0); log as the runtime's libm would
-    acc = (prob1 > r.prob0) || ((prob1 - r.prob0) / TT > log(uu));
+    acc = (prob1 > r.prob0) || ((prob1 - r.prob0) / TT > det_log(uu));
     if (acc) {
       r.th = thp;
       r.prob0 = prob1;

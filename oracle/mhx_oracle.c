@@ -447,6 +447,153 @@ double orc_logpost(const orc_problem* p, const double* theta, double* parts) {
   return ll + lp;
 }
 
+/* ======================================================================== */
+/* MIRROR mode: the same posterior in the GPU kernel's own arithmetic          */
+/* ======================================================================== */
+/* The faithful functions above follow the reference (serial sums, libm, divisions).  The
+ * mirror follows lisp-mcmc_amd/csrc for problems made of GAUSS_PEAKS functions with the
+ * normal likelihood (BASELINE config 2's kernel): 1/sigma and y/sigma formed once, exp as
+ * 2^(-t^2) with the exponent built inside two fmas and a degree-11 polynomial, lane-strided
+ * accumulation (lane l of 64 takes points l, l+64, ...; two accumulators alternate) and the
+ * xor butterfly.  fma() here is the C99 correctly rounded one, so the result is BIT-IDENTICAL
+ * to the device's.  It exists to turn "within tolerance" into "equal" in the tests; the
+ * tolerance between mirror and faithful is checked on the CPU. */
+static double mir_exp2_negsq(double t) {
+  const double MAGIC = 0x1.8p52;
+  double kd = fma(-t, t, MAGIC);
+  double kf = kd - MAGIC;
+  double f = fma(-t, t, -kf);
+  double p = 0x1.e9d3fe3952179p-32;
+  p = fma(p, f, 0x1.e6063f7217bc6p-28);
+  p = fma(p, f, 0x1.b524fae627834p-24);
+  p = fma(p, f, 0x1.62bfd47773353p-20);
+  p = fma(p, f, 0x1.ffcbfc670dcd4p-17);
+  p = fma(p, f, 0x1.430913096fd9fp-13);
+  p = fma(p, f, 0x1.5d87fe78a5276p-10);
+  p = fma(p, f, 0x1.3b2ab6fba1ddap-7);
+  p = fma(p, f, 0x1.c6b08d704a0c2p-5);
+  p = fma(p, f, 0x1.ebfbdff82c598p-3);
+  p = fma(p, f, 0x1.62e42fefa39efp-1);
+  p = fma(p, f, 1.0);
+  return ldexp(p, (int)(int32_t)(uint32_t)to_bits(kd)); /* low dword of 1.5*2^52 + k is k */
+}
+
+static double mir_dexp(double x) {
+  const double MAGIC = 0x1.8p52;
+  double kd = fma(x, 1.4426950408889634074, MAGIC);
+  double kf = kd - MAGIC;
+  double r = fma(-kf, 6.93147180369123816490e-01, x);
+  r = fma(-kf, 1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)kf);
+}
+
+static double mir_bound_penalty(double p, double lo, double hi) {
+  if (lo < p && p < hi) return 0.0;
+  double a = fabs(p - hi), b = fabs(p - lo);
+  double m = a < b ? a : b;
+  return -1e10 * (mir_dexp(m * 1e-5) - 1.0);
+}
+
+#define MIR_LANES 64
+#define MIR_TILE 1024
+
+/* returns NaN with *supported = 0 when the problem is outside the mirrored kernel */
+static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported) {
+  double local[MHX_MAX_FN_PARAMS];
+  gather(f, theta, local);
+  if (f->model != MHX_MODEL_GAUSS_PEAKS || f->lik != MHX_LIK_NORMAL) {
+    *supported = 0;
+    return NAN;
+  }
+  const int nbg = f->shape[0], npk = f->shape[1];
+  const double ksl2e = 1.2011224087864497594; /* sqrt(log2 e) */
+  double iw[MHX_MAX_FN_PARAMS], cc[MHX_MAX_FN_PARAMS], A[MHX_MAX_FN_PARAMS];
+  double xmin = f->n ? f->x[0] : 0.0, xmax = xmin;
+  for (size_t i = 1; i < f->n; ++i) {
+    if (f->x[i] < xmin) xmin = f->x[i];
+    if (f->x[i] > xmax) xmax = f->x[i];
+  }
+  for (int k = 0; k < npk; ++k) {
+    A[k] = local[nbg + 3 * k];
+    iw[k] = ksl2e / local[nbg + 3 * k + 2];
+    cc[k] = -local[nbg + 3 * k + 1] * iw[k];
+    /* the kernel's fast path (|t| < 46000 over the data range); anything else takes a
+     * differently rounded guarded path that is not mirrored */
+    double ta = fabs(fma(xmin, iw[k], cc[k])), tb = fabs(fma(xmax, iw[k], cc[k]));
+    if (!(ta < 46000.0) || !(tb < 46000.0)) {
+      *supported = 0;
+      return NAN;
+    }
+  }
+  double acc0[MIR_LANES] = {0}, acc1[MIR_LANES] = {0};
+  long double csum = 0.0L;
+  const double half_log_2pi = -0.5 * log(2.0 * M_PI);
+  for (size_t i = 0; i < f->n; ++i) {
+    const double s = f->sigma[i];
+    const double w = 1.0 / s, yw = f->y[i] * w, x = f->x[i];
+    csum += (long double)(half_log_2pi + (-1.0 * log(s)));
+    double m = nbg > 0 ? local[nbg - 1] : 0.0;
+    for (int j = nbg - 2; j >= 0; --j) m = fma(m, x, local[j]);
+    for (int k = 0; k < npk; ++k) m = fma(A[k], mir_exp2_negsq(fma(x, iw[k], cc[k])), m);
+    const double r = fma(-m, w, yw);
+    const size_t in_tile = i % MIR_TILE, lane = in_tile % MIR_LANES, kk = in_tile / MIR_LANES;
+    if (kk & 1)
+      acc1[lane] = fma(r, r, acc1[lane]);
+    else
+      acc0[lane] = fma(r, r, acc0[lane]);
+  }
+  double v[MIR_LANES], nv[MIR_LANES];
+  for (int l = 0; l < MIR_LANES; ++l) v[l] = acc0[l] + acc1[l];
+  for (int m = 32; m >= 1; m >>= 1) {
+    for (int l = 0; l < MIR_LANES; ++l) nv[l] = v[l] + v[l ^ m];
+    memcpy(v, nv, sizeof v);
+  }
+  return fma(-0.5, v[0], (double)csum);
+}
+
+static double mir_logprior_fn(const orc_fn* f, const double* theta) {
+  if (f->n_bounds == 0) return 0.0;
+  double acc = 0.0;
+  for (int i = 0; i < f->n_bounds; ++i) {
+    double v = f->bidx[i] >= 0 ? theta[f->bidx[i]] : 0.0;
+    double b = mir_bound_penalty(v, f->blo[i], f->bhi[i]);
+    acc = i == 0 ? b : acc + b;
+  }
+  return acc;
+}
+
+/* the kernel's value of walker-make-step's prob; NaN when the problem is not mirrored */
+double orc_logpost_mirror(const orc_problem* p, const double* theta, double* parts) {
+  int ok = 1;
+  double ll = 0.0, lp = 0.0;
+  for (int k = 0; k < p->K && ok; ++k) {
+    double v = mir_loglik_fn(&p->fn[k], theta, &ok);
+    ll = k == 0 ? v : ll + v;
+    double q = mir_logprior_fn(&p->fn[k], theta);
+    lp = k == 0 ? q : lp + q;
+  }
+  if (!ok) return NAN;
+  if (parts) {
+    parts[0] = ll;
+    parts[1] = lp;
+  }
+  return ll + lp;
+}
+
 double orc_logpost_abs_terms(const orc_problem* p, const double* theta) {
   double s = 0.0, local[MHX_MAX_FN_PARAMS];
   for (int k = 0; k < p->K; ++k) {
@@ -474,6 +621,7 @@ struct orc_walker {
   /* controller state, M:866-879 */
   int64_t n, i, sts, temp_steps, reset_index, mwl;
   int auto_mode, shutting_down, status, estop, has_mwl;
+  int mirror; /* evaluate the posterior and log u in the kernel's arithmetic (mirror mode) */
   double temperature;
   double* temps;
   double L[MHX_MAX_PARAMS * MHX_MAX_PARAMS];
@@ -492,11 +640,16 @@ static void hist_push(orc_walker* w, double prob, const double* theta) {
 }
 
 /* M:1132-1163: first step's prob, walk = (first-step), length 1, age 1 */
-orc_walker* orc_walker_create(const orc_problem* p, const double* theta0) {
+static double walker_logpost(const orc_walker* w, const double* theta) {
+  return w->mirror ? orc_logpost_mirror(w->p, theta, NULL) : orc_logpost(w->p, theta, NULL);
+}
+
+orc_walker* orc_walker_create2(const orc_problem* p, const double* theta0, int mirror) {
   orc_walker* w = (orc_walker*)calloc(1, sizeof(*w));
   w->p = p;
   w->d = p->d;
-  double pr = orc_logpost(p, theta0, NULL);
+  w->mirror = mirror;
+  double pr = walker_logpost(w, theta0);
   hist_push(w, pr, theta0);
   w->length = 1;
   w->age = 1;
@@ -504,6 +657,9 @@ orc_walker* orc_walker_create(const orc_problem* p, const double* theta0) {
   memcpy(w->best_theta, theta0, sizeof(double) * (size_t)w->d);
   w->status = ORC_DONE;
   return w;
+}
+orc_walker* orc_walker_create(const orc_problem* p, const double* theta0) {
+  return orc_walker_create2(p, theta0, 0);
 }
 void orc_walker_destroy(orc_walker* w) {
   if (!w) return;
@@ -647,9 +803,9 @@ int orc_walker_take_step_injected(orc_walker* w, const double* L, const double* 
   double prev[MHX_MAX_PARAMS], next[MHX_MAX_PARAMS];
   memcpy(prev, w->theta + l * (size_t)d, sizeof(double) * (size_t)d);
   orc_covariant_sample(prev, L, z, d, next);
-  double prob1 = orc_logpost(w->p, next, NULL);
+  double prob1 = walker_logpost(w, next);
   if (!isfinite(prob1)) return -1; /* a trap (or a complex/type error) in the reference */
-  int acc = (prob1 > prob0) || ((prob1 - prob0) / T > log(u));
+  int acc = (prob1 > prob0) || ((prob1 - prob0) / T > (w->mirror ? orc_det_log(u) : log(u)));
   if (acc)
     add_step(w, prob1, next);
   else

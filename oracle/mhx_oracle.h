@@ -80,11 +80,16 @@ int orc_problem_set_bounds(orc_problem* p, int k, const int32_t* idx, const doub
 void orc_problem_set_logfact_double(orc_problem* p, int flag);
 /* walker-make-step's prob (M:1067-1070); parts[0] = sum ll, parts[1] = sum lp */
 double orc_logpost(const orc_problem* p, const double* theta, double* parts);
+/* MIRROR of the GPU kernel's arithmetic (GAUSS_PEAKS + normal likelihood problems only, NaN
+ * otherwise): bit-identical to the device, see mhx_oracle.c */
+double orc_logpost_mirror(const orc_problem* p, const double* theta, double* parts);
 /* sum_i |term_i| over all likelihood points: the scale of the stated tolerance */
 double orc_logpost_abs_terms(const orc_problem* p, const double* theta);
 
 /* ---- walker (M:462-581, M:1067-1163) -------------------------------------- */
 orc_walker* orc_walker_create(const orc_problem* p, const double* theta0);
+/* mirror != 0: posterior and log u in the kernel's arithmetic (bit-comparable runs) */
+orc_walker* orc_walker_create2(const orc_problem* p, const double* theta0, int mirror);
 void orc_walker_destroy(orc_walker* w);
 /* walker-take-step (M:1072-1095) with the caller's randomness; returns 1 accepted,
  * 0 rejected, -1 the reference would have trapped (walker unchanged) */

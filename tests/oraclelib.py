@@ -69,6 +69,8 @@ def lib():
         "orc_logpost": (d, [vp, f64p, f64p]),
         "orc_logpost_abs_terms": (d, [vp, f64p]),
         "orc_walker_create": (vp, [vp, f64p]),
+        "orc_walker_create2": (vp, [vp, f64p, i]),
+        "orc_logpost_mirror": (d, [vp, f64p, f64p]),
         "orc_walker_destroy": (None, [vp]),
         "orc_walker_take_step_injected": (i, [vp, f64p, f64p, d, d]),
         "orc_walker_modify": (i, [vp, i, C.c_int64]),
@@ -153,6 +155,13 @@ class Problem:
         v = lib().orc_logpost(self.h, tp, pr.ctypes.data_as(f64p))
         return (v, pr) if parts else v
 
+    def logpost_mirror(self, theta, parts=False):
+        """the GPU kernel's arithmetic on the CPU (NaN when the problem is not mirrored)"""
+        th, tp = _f64(theta)
+        pr = np.zeros(2)
+        v = lib().orc_logpost_mirror(self.h, tp, pr.ctypes.data_as(f64p))
+        return (v, pr) if parts else v
+
     def logpost_many(self, thetas):
         thetas = np.ascontiguousarray(thetas, dtype=np.float64).reshape(-1, self.d)
         return np.array([self.logpost(t) for t in thetas])
@@ -163,11 +172,11 @@ class Problem:
 
 
 class Walker:
-    def __init__(self, problem, theta0):
+    def __init__(self, problem, theta0, mirror=False):
         self.p = problem
         self.d = problem.d
         th, tp = _f64(theta0)
-        self.h = lib().orc_walker_create(problem.h, tp)
+        self.h = lib().orc_walker_create2(problem.h, tp, int(bool(mirror)))
 
     def __del__(self):
         if getattr(self, "h", None):

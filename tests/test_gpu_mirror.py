@@ -1,0 +1,82 @@
+"""Bit-for-bit parity of BASELINE config 2's kernel with the oracle's mirror mode: the mirror
+restates the kernel's arithmetic on the CPU (and is itself held to the reference's arithmetic
+within the stated tolerance by tests/test_oracle_mirror.py), so here EVERYTHING is compared for
+equality: log-posteriors, their likelihood and prior parts, whole histories of
+walker-adaptive-steps runs."""
+import numpy as np
+import pytest
+
+import problems as pb
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mhx():
+    import lisp_mcmc_amd
+    return lisp_mcmc_amd
+
+
+@pytest.mark.parametrize("n", [1, 64, 65, 1023, 1024, 1025, 3000, 100000])
+def test_logpost_equals_mirror(mhx, orc, n):
+    s = pb.two_peak(n=n, seed=100 + n)
+    op = s.oracle(orc)
+    e = s.engine(mhx, 1)
+    th = pb.perturbed(s.theta_star, 13, 0.03, seed=n)
+    th[1] = s.theta_star * 1.7
+    th[2, 0] = -3.0
+    got, parts = e.logpost(th, parts=True)
+    for i, t in enumerate(th):
+        ref, rp = op.logpost_mirror(t, parts=True)
+        assert got[i] == ref and parts[i, 0] == rp[0] and parts[i, 1] == rp[1], (n, i)
+    e.close()
+
+
+def test_injected_steps_equal_mirror(mhx, orc):
+    s = pb.two_peak(n=1500, seed=7)
+    op = s.oracle(orc)
+    C_, d = 9, s.d
+    rng = np.random.default_rng(0)
+    e = s.engine(mhx, C_)
+    th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=1)
+    e.init_chains(th0)
+    ws = [orc.Walker(op, th0[c], mirror=True) for c in range(C_)]
+    L = np.diag(0.02 * np.abs(s.theta_star))
+    for it in range(80):
+        z = rng.standard_normal((C_, d))
+        u = 1.0 - rng.random(C_)
+        T = rng.uniform(1.0, 10.0, C_)
+        acc = e.step_injected(L, z, u, T)
+        st = e.state()
+        for c, w in enumerate(ws):
+            assert w.take_step_injected(L, z[c], u[c], T[c]) == acc[c]
+            th, pr = w.last()
+            assert np.array_equal(st["theta"][c], th) and st["logpost"][c] == pr, (it, c)
+    e.close()
+
+
+def test_adaptive_run_history_equals_mirror(mhx, orc):
+    """a complete walker-adaptive-steps run (annealing, bound excursions, L updates, auto
+    shutdown): the newest 1000 (prob, theta) pairs, L, T and loop index all equal"""
+    s = pb.two_peak(n=800, seed=8)
+    op = s.oracle(orc)
+    C_, n = 6, 5000
+    e = s.engine(mhx, C_, seed=31)
+    th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=2)
+    e.init_chains(th0)
+    e.adaptive_begin(n, 10.0, 1)
+    e.adaptive_advance(1 << 40)
+    st = e.state()
+    status, loop_i = e.chain_status()
+    Ls = e.lmatrix()
+    for c in range(C_):
+        w = orc.Walker(op, th0[c], mirror=True)
+        w.adaptive_begin(n, 10.0, 1, seed=31, chain_id=c)
+        assert w.adaptive_advance(1 << 40) == orc.DONE and status[c] == 1
+        assert loop_i[c] == w.loop_index and st["age"][c] == w.age
+        pg, tg = e.trace(c, 1000)
+        po, to = w.trace(1000)
+        assert np.array_equal(pg, po) and np.array_equal(tg, to), c
+        assert np.array_equal(Ls[c], w.current_l())
+        assert st["best_logpost"][c] == w.best()[1]
+    e.close()

@@ -1,0 +1,49 @@
+"""The oracle's MIRROR mode (the GPU kernel's own arithmetic, restated on the CPU) against its
+faithful mode (the reference's arithmetic): the stated tolerance, checked without a GPU.  The
+GPU tests then require the device to EQUAL the mirror bit for bit."""
+import numpy as np
+import pytest
+
+import problems as pb
+
+REL = 1e-12
+PRIOR_ULP = 2.0 ** -52 * 1e10
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 1024, 1025, 5000, 100000])
+def test_mirror_within_tolerance_of_faithful(orc, n):
+    s = pb.two_peak(n=n, seed=n + 1)
+    op = s.oracle(orc)
+    th = pb.perturbed(s.theta_star, 6, 0.03, seed=n)
+    th[1] = s.theta_star * 1.7      # every bound violated
+    th[2, 4] *= 0.3                 # a narrow peak
+    for t in th:
+        a, pa = op.logpost(t, parts=True)
+        b, pm = op.logpost_mirror(t, parts=True)
+        nv = int(((t <= s.bounds[0][1]) | (t >= s.bounds[0][2])).sum())
+        assert abs(pa[0] - pm[0]) <= REL * op.abs_terms(t)
+        assert abs(pa[1] - pm[1]) <= 4 * PRIOR_ULP * nv
+        assert (pa[1] == 0.0) == (pm[1] == 0.0)
+
+
+def test_mirror_declines_what_the_kernel_does_differently(orc):
+    s = pb.two_peak(n=100, seed=3)
+    op = s.oracle(orc)
+    th = s.theta_star.copy()
+    th[4] = 1e-6                     # |t| > 46000 somewhere: the kernel's guarded path
+    assert np.isnan(op.logpost_mirror(th)) and np.isfinite(op.logpost(th))
+    p = pb.poisson_peaks(n=50).oracle(orc)
+    assert np.isnan(p.logpost_mirror(pb.poisson_peaks(n=50).theta_star))
+
+
+def test_mirror_walker_tracks_faithful_walker(orc):
+    s = pb.two_peak(n=300, seed=5)
+    op = s.oracle(orc)
+    a = orc.Walker(op, s.theta_star)
+    b = orc.Walker(op, s.theta_star, mirror=True)
+    for w in (a, b):
+        w.adaptive_begin(2500, 10.0, 1, seed=9, chain_id=4)
+        assert w.adaptive_advance(1 << 40) == orc.DONE
+    assert a.age == b.age
+    assert np.array_equal(a.last()[0], b.last()[0])          # same accept decisions throughout
+    assert abs(a.last()[1] - b.last()[1]) <= REL * op.abs_terms(a.last()[0])
