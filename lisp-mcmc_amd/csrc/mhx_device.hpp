@@ -188,12 +188,15 @@ __device__ __forceinline__ double mexp2(double s) {
 // Valid for |t| < 46340 (t^2 < 2^31): then k is the low dword of kd, no conversion needed.
 // Callers establish the bound once per step from the dataset's x range (Prep::fast).
 // 14 VALU instructions.
-__device__ __forceinline__ double mexp2_negsq(double t) {
+// c11 = kExp2C11, handed in from a VGPR the caller keeps alive across its loop: the first
+// Horner step reads two constants, and only one may come from the scalar file
+constexpr double kExp2C11 = 0x1.e9d3fe3952179p-32;
+__device__ __forceinline__ double mexp2_negsq(double t, double c11 = kExp2C11) {
   const double MAGIC = 0x1.8p52;
   const double kd = __builtin_fma(-t, t, MAGIC);
   const double kf = kd - MAGIC;
   const double f = __builtin_fma(-t, t, -kf);
-  double p = 0x1.e9d3fe3952179p-32;
+  double p = c11;
   p = __builtin_fma(p, f, 0x1.e6063f7217bc6p-28);
   p = __builtin_fma(p, f, 0x1.b524fae627834p-24);
   p = __builtin_fma(p, f, 0x1.62bfd47773353p-20);
@@ -298,6 +301,9 @@ struct PeaksModel {
   struct Prep {
     double bg[NBG > 0 ? NBG : 1];
     double A[NPK], mu[NPK], iw[NPK];
+    double cv[NPK];  // mu[] once more, pinned in VGPRs: t = fma(x, iw, c) may read only ONE
+                     // scalar operand (constant bus), so c would be re-copied for every point
+    double c11;      // leading coefficient of the 2^f polynomial, pinned likewise
     bool fast;  // |t| < 46000 over the whole x range for every peak (uniform)
   };
   template <class PF>
@@ -306,6 +312,11 @@ struct PeaksModel {
     bool fast = true;
 #pragma unroll
     for (int j = 0; j < NBG; ++j) p.bg[j] = uniform_f64(pf(j));
+    if (NBG > 1) {  // the first Horner step reads two coefficients: keep the leading one in a VGPR
+      double lead = p.bg[NBG - 1];
+      asm volatile("" : "+v"(lead));
+      p.bg[NBG - 1] = lead;
+    }
 #pragma unroll
     for (int k = 0; k < NPK; ++k) {
       p.A[k] = uniform_f64(pf(NBG + 3 * k));
@@ -314,12 +325,18 @@ struct PeaksModel {
       const double iw = LORENTZ ? 1.0 / pf(NBG + 3 * k + 2) : kSqrtLog2e / pf(NBG + 3 * k + 2);
       p.iw[k] = uniform_f64(iw);
       p.mu[k] = uniform_f64(-mu * iw);  // additive constant of the fma below
+      double cvk = p.mu[k];
+      asm volatile("" : "+v"(cvk));
+      p.cv[k] = cvk;
       // t is linear in x: its extremes sit at the ends of the data range (NaN fails the test)
       const double ta = fabs(__builtin_fma(fn.xmin, p.iw[k], p.mu[k]));
       const double tb = fabs(__builtin_fma(fn.xmax, p.iw[k], p.mu[k]));
       fast = fast && (ta < 46000.0) && (tb < 46000.0);
     }
     p.fast = fast;
+    double c11 = kExp2C11;
+    asm volatile("" : "+v"(c11));
+    p.c11 = c11;
     return p;
   }
   static __device__ __forceinline__ bool fast_ok(const Prep& p) { return p.fast; }
@@ -333,11 +350,11 @@ struct PeaksModel {
     }
 #pragma unroll
     for (int k = 0; k < NPK; ++k) {
-      const double t = __builtin_fma(x, p.iw[k], p.mu[k]);
+      const double t = __builtin_fma(x, p.iw[k], p.cv[k]);
       if (LORENTZ)
         f = __builtin_fma(p.A[k], frcp(__builtin_fma(t, t, 1.0)), f);
       else
-        f = __builtin_fma(p.A[k], FAST ? mexp2_negsq(t) : mexp2_negsq_safe(t), f);
+        f = __builtin_fma(p.A[k], FAST ? mexp2_negsq(t, p.c11) : mexp2_negsq_safe(t), f);
     }
     return f;
   }
