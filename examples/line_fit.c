@@ -48,9 +48,9 @@ int main(void) {
   TRY(mhx_get_state(e, th, &lp, best, &best_lp, &length, &age));
   double acc;
   TRY(mhx_get_acceptance(e, 1000, &acc));
-  printf("after %lld steps: most likely b = %.4f m = %.4f (least squares 1.7923 1.2179), "
+  printf("after %lld steps: most likely b = %.4f m = %.4f (least squares 3.4778 0.9676), "
          "prob %.4f, acceptance(1000) %.3f\n",
          (long long)(age - 1), best[0], best[1], best_lp, acc);
   mhx_destroy(e);
-  return (fabs(best[0] - 1.7923) < 0.2 && fabs(best[1] - 1.2179) < 0.05) ? 0 : 3;
+  return (fabs(best[0] - 3.4778) < 0.2 && fabs(best[1] - 0.9676) < 0.05) ? 0 : 3;
 }
