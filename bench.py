@@ -163,13 +163,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if args.warmup > 0:
-        e.adaptive_advance(args.warmup, count=False)
+    # Every launch of the step kernel - warm-up and timed alike - runs the same number of loop
+    # iterations, so that rocprofv3's per-kernel average duration (profiles/) is directly
+    # comparable with the HIP-event average reported below.
+    import math
+    per_launch = math.gcd(args.steps, args.warmup) if args.warmup > 0 else args.steps
+    for _ in range(args.warmup // per_launch if args.warmup > 0 else 0):
+        e.adaptive_advance(per_launch, count=False)
     e.kernel_timing(reset=True)
     steps0 = e.counters()[0]
     sync()
     t0 = time.perf_counter()
-    e.adaptive_advance(args.steps, count=False)  # one launch, K loop iterations per chain
+    for _ in range(args.steps // per_launch):
+        e.adaptive_advance(per_launch, count=False)  # one launch = per_launch fused iterations
     sync()
     t1 = time.perf_counter()
     el = t1 - t0
@@ -216,6 +222,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_chain_step": bytes_step,
                      "kernel_ms_per_launch": kt["avg_ms"], "launches": kt["launches"],
+                     "iterations_per_launch": per_launch,
                      "note": "dataset is L2/MALL resident and shared by the chains of a workgroup "
                              "through LDS; the kernel is fp64-VALU bound (DESIGN.md)"},
     }
@@ -226,7 +233,10 @@ def main():
     if os.path.exists(prof) and world == 1:
         try:
             ps = json.load(open(prof))
-            prof_steps = ps["bench_stats"]["steps"] * ps["bench_stats"]["config"]["chains_per_gpu"]
+            # the summary's counters belong to ONE launch (the last one of the profiled run)
+            bs = ps["bench_stats"]
+            prof_steps = (bs["roofline"].get("iterations_per_launch", bs["steps"])
+                          * bs["config"]["chains_per_gpu"])
             per_step = (ps["hbm_read_bytes"] + ps["hbm_write_bytes"]) / prof_steps
             out["roofline"]["traffic"] = per_step * chain_steps
             out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(prof)
