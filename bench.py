@@ -238,7 +238,8 @@ def main():
             prof_steps = (bs["roofline"].get("iterations_per_launch", bs["steps"])
                           * bs["config"]["chains_per_gpu"])
             per_step = (ps["hbm_read_bytes"] + ps["hbm_write_bytes"]) / prof_steps
-            out["roofline"]["traffic"] = per_step * chain_steps
+            out["roofline"]["traffic"] = per_step * per_launch * chains  # per launch, like `achieved`
+            out["roofline"]["algorithmic_bytes_per_launch"] = bytes_step * per_launch * chains
             out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(prof)
         except Exception:  # a malformed summary must not break the benchmark
             pass

@@ -103,7 +103,9 @@ enum {
 enum {
   MHX_LIK_NORMAL = 0,        /* log-liklihood-normal (+ README weighted form) M:393-400 */
   MHX_LIK_NORMAL_CUTOFF = 1, /* log-liklihood-normal-cutoff, each term >= -5000 M:419-427 */
-  MHX_LIK_POISSON = 2        /* log-poisson over points, M:379-383 via M:402-416      */
+  MHX_LIK_POISSON = 2,       /* log-poisson over points, M:379-383 via M:402-416      */
+  MHX_LIK_EXPR = 3           /* create-log-liklihood-function M:402-416: the per-point term
+                                is the expression given to mhx_set_likelihood_expr       */
 };
 
 /* ---- adaptation modes --------------------------------------------------- */
@@ -195,6 +197,14 @@ int mhx_set_function_expr(mhx_engine* e, int k, const char* expr, const char* co
  * (names[i] = theta[index[i]]), e.g. NV's "bounds_total + (mu1 > mu2 ? -1e9 : 0.0)". */
 int mhx_set_prior_expr(mhx_engine* e, int k, const char* expr, const char* const* names,
                        const int32_t* index, int n);
+/* Per-point log-likelihood of function k as an expression: the closure handed to
+ * create-log-liklihood-function (M:402-416), (lambda (y model error) <body>), with `y` the
+ * measured value, `model` the model's prediction at that x and `error` the point's sigma as
+ * its docstring defines them (the reference's code passes the WHOLE stddev list as the third
+ * argument, M:415, so only bodies that ignore `error` ever ran there).  The log-likelihood is
+ * the plain sum of the terms over the points.  Dataset k must have been set with
+ * MHX_LIK_EXPR (x, y, sigma are kept as given) and function k with mhx_set_function_expr. */
+int mhx_set_likelihood_expr(mhx_engine* e, int k, const char* expr);
 /* First step of every chain (M:1148-1150): theta0 is [n_chains][d], or [d] when
  * broadcast != 0.  Resets history, age, length, most-likely step. */
 int mhx_init_chains(mhx_engine* e, const double* theta0, int broadcast);

@@ -21,10 +21,10 @@ from .saveload import walker_save, walker_load  # noqa: F401
 from .walker import (  # noqa: F401
     Walker, WalkerStep, walker_create, mcmc_fit, walker_adaptive_steps,
     walker_adaptive_steps_full, walker_many_steps, walker_take_step, walker_get,
-    walker_modify, prior_bounds, log_prior_flat, request_stop,
+    walker_modify, prior_bounds, log_prior_flat, request_stop, create_log_liklihood_function,
 )
 
 __all__ = ["capi", "MhxError", "Engine", "models", "Walker", "WalkerStep", "walker_create",
            "mcmc_fit", "walker_adaptive_steps", "walker_adaptive_steps_full",
            "walker_many_steps", "walker_take_step", "walker_get", "walker_modify",
-           "prior_bounds", "log_prior_flat", "request_stop"]
+           "prior_bounds", "log_prior_flat", "request_stop", "create_log_liklihood_function"]

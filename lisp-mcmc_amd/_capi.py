@@ -20,7 +20,7 @@ u64p = C.POINTER(C.c_uint64)
 OK, EINVAL, ENOMEM, EDEVICE, ESTATE, EUNSUPPORTED, ECOMM = 0, -1, -2, -3, -4, -5, -6
 MODEL_POLY, MODEL_GAUSS_PEAKS, MODEL_LORENTZ_PEAKS, MODEL_LORDER_MIXED = 0, 1, 2, 3
 MODEL_EXP_DECAY, MODEL_SINUSOID, MODEL_PVOIGT2, MODEL_EXPR = 4, 5, 6, 7
-LIK_NORMAL, LIK_NORMAL_CUTOFF, LIK_POISSON = 0, 1, 2
+LIK_NORMAL, LIK_NORMAL_CUTOFF, LIK_POISSON, LIK_EXPR = 0, 1, 2, 3
 ADAPT_FAITHFUL, ADAPT_POOLED = 0, 1
 CHAIN_RUNNING, CHAIN_DONE, CHAIN_FP_TRAP, CHAIN_STOPPED = 0, 1, 2, 3
 L_OK, L_CAUGHT, L_INVALID, L_EMPTY = 0, 1, 2, 3
@@ -55,6 +55,7 @@ SIGNATURES = {
                                         i32p, C.c_int]),
     "mhx_set_prior_expr": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_char_p),
                                      i32p, C.c_int]),
+    "mhx_set_likelihood_expr": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p]),
     "mhx_init_chains": (C.c_int, [C.c_void_p, f64p, C.c_int]),
     "mhx_logpost": (C.c_int, [C.c_void_p, f64p, C.c_size_t, f64p, f64p]),
     "mhx_step_injected": (C.c_int, [C.c_void_p, f64p, C.c_int, f64p, f64p, f64p, u8p]),

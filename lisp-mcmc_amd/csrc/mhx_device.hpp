@@ -290,6 +290,33 @@ __device__ __forceinline__ double frcp(double d) {
   y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
   return y;
 }
+// e^x, < 1 ulp: the `exp` of user expressions (mhx_rtc.cpp) - 17 VALU instructions where
+// ocml's exp takes about 37.  k = rint(x log2 e) by the magic-number trick, f = x log2 e - k
+// from a hi/lo split of log2 e (the inner fma cancels k, so f keeps an absolute error of
+// 2^-54), 2^f by mexp2's polynomial, scaled by ldexp with the SATURATING conversion of k, so
+// that x > 709.8 gives inf and x < -745.2 gives 0 with no range test.  NaN -> NaN.  x = +-inf
+// -> NaN as well: an infinite argument can only come from an operation SBCL would already have
+// trapped on (overflow), and a NaN log-posterior marks the chain as trapped.  For finite
+// |x| >= 2^51 / log2 e the result is 0 or an infinity of either sign.
+__device__ __forceinline__ double gexp(double x) {
+  const double MAGIC = 0x1.8p52, L2E_HI = 0x1.71547652b82fep+0, L2E_LO = 0x1.777d0ffda0d24p-56;
+  const double kd = __builtin_fma(x, L2E_HI, MAGIC);
+  const double kf = kd - MAGIC;
+  const double f = __builtin_fma(x, L2E_LO, __builtin_fma(x, L2E_HI, -kf));
+  double p = 0x1.e9d3fe3952179p-32;
+  p = __builtin_fma(p, f, 0x1.e6063f7217bc6p-28);
+  p = __builtin_fma(p, f, 0x1.b524fae627834p-24);
+  p = __builtin_fma(p, f, 0x1.62bfd47773353p-20);
+  p = __builtin_fma(p, f, 0x1.ffcbfc670dcd4p-17);
+  p = __builtin_fma(p, f, 0x1.430913096fd9fp-13);
+  p = __builtin_fma(p, f, 0x1.5d87fe78a5276p-10);
+  p = __builtin_fma(p, f, 0x1.3b2ab6fba1ddap-7);
+  p = __builtin_fma(p, f, 0x1.c6b08d704a0c2p-5);
+  p = __builtin_fma(p, f, 0x1.ebfbdff82c598p-3);
+  p = __builtin_fma(p, f, 0x1.62e42fefa39efp-1);
+  p = __builtin_fma(p, f, 1.0);
+  return ldexp(p, (int)kf);  // v_cvt_i32_f64 saturates
+}
 constexpr double kLog2e = 1.4426950408889634074;       // log2(e)
 constexpr double kSqrtLog2e = 1.2011224087864497594;   // sqrt(log2(e))
 // exp(s) through mexp2 (relative error ~ 2 ulp * |s|: callers use it on decaying terms)

@@ -98,6 +98,7 @@ struct mhx_engine {
   bool problem_dirty = true;
   UserExpr fn_expr[MHX_MAX_FUNCTIONS];     // MHX_MODEL_EXPR bodies
   UserExpr prior_expr[MHX_MAX_FUNCTIONS];  // prior-bounds-let bodies
+  std::string lik_expr[MHX_MAX_FUNCTIONS]; // create-log-liklihood-function bodies (validated)
   std::unique_ptr<UserProgram> user_prog;
   std::string user_key;
   int spec = SPEC_GENERIC;
@@ -144,12 +145,25 @@ int finalize_problem(mhx_engine* e) {
   }
   // expression models / prior bodies: assign slots, compile once per distinct problem text
   std::vector<UserExpr> models, priors;
+  bool builtin = false;
   for (int k = 0; k < e->P.K; ++k) {
     FnDesc& f = e->P.fn[k];
     f.user_slot = f.prior_slot = -1;
+    if (f.lik == MHX_LIK_EXPR) {
+      if (e->lik_expr[k].empty())
+        return fail(MHX_ESTATE, "dataset %d uses MHX_LIK_EXPR but mhx_set_likelihood_expr was "
+                                "never called for it", k);
+      if (f.model != MHX_MODEL_EXPR)
+        return fail(MHX_EUNSUPPORTED, "function %d: an expression likelihood needs an expression "
+                                      "model (mhx_set_function_expr)", k);
+    }
     if (f.model == MHX_MODEL_EXPR) {
       f.user_slot = (int)models.size();
       models.push_back(e->fn_expr[k]);
+      models.back().lik = f.lik;
+      if (f.lik == MHX_LIK_EXPR) models.back().lik_expr = e->lik_expr[k];
+    } else {
+      builtin = true;
     }
     if (!e->prior_expr[k].expr.empty()) {
       f.prior_slot = (int)priors.size();
@@ -159,12 +173,20 @@ int finalize_problem(mhx_engine* e) {
   HIP_TRY(hipMemcpy(e->dP.p, &e->P, sizeof(ProblemDesc), hipMemcpyHostToDevice));
   if (!models.empty() || !priors.empty()) {
     std::string key;
-    for (auto& u : models) key += "M:" + u.expr + "|";
-    for (auto& u : priors) key += "P:" + u.expr + "|";
+    auto sig = [](const UserExpr& u) {  // the generated code depends on names and their order
+      std::string s;
+      for (size_t j = 0; j < u.names.size(); ++j)
+        s += u.names[j] + "=" + std::to_string(u.index[j]) + ",";
+      return s;
+    };
+    for (auto& u : models)
+      key += "M:" + u.expr + "|" + sig(u) + "|L" + std::to_string(u.lik) + ":" + u.lik_expr + "|";
+    for (auto& u : priors) key += "P:" + u.expr + "|" + sig(u) + "|";
+    key += builtin ? "B1" : "B0";
     if (!e->user_prog || key != e->user_key) {
       std::unique_ptr<UserProgram> prog(new UserProgram());
       std::string err;
-      if (rtc_build(models, priors, e->P.d, prog.get(), &err) != 0)
+      if (rtc_build(models, priors, builtin, prog.get(), &err) != 0)
         return fail(MHX_EUNSUPPORTED, "%s", err.c_str());
       e->user_prog = std::move(prog);
       e->user_key = key;
@@ -489,7 +511,7 @@ int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y, cons
   if (!e) return fail(MHX_EINVAL, "engine is NULL");
   if (k < 0 || k >= e->P.K) return fail(MHX_EINVAL, "dataset index %d out of range", k);
   if (n > 0 && (!x || !y)) return fail(MHX_EINVAL, "x/y is NULL");
-  if (likelihood < MHX_LIK_NORMAL || likelihood > MHX_LIK_POISSON)
+  if (likelihood < MHX_LIK_NORMAL || likelihood > MHX_LIK_EXPR)
     return fail(MHX_EINVAL, "unknown likelihood %d", likelihood);
   int rc = use_device(e);
   if (rc != MHX_OK) return rc;
@@ -509,6 +531,9 @@ int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y, cons
       hc[i] = 0.0;
       csum -= (long double)log_factorial_ref((long)y[i], e->cfg.poisson_logfact_double != 0,
                                              lf_cache);
+    } else if (likelihood == MHX_LIK_EXPR) {
+      hw[i] = sigma ? sigma[i] : 1.0;  // handed to the expression as `error`, untouched
+      hc[i] = 0.0;
     } else {
       const double s = sigma ? sigma[i] : 1.0;  // (if data-error data-error 1) M:1144
       if (!(s > 0.0) || !std::isfinite(s))
@@ -635,6 +660,18 @@ int mhx_set_prior_expr(mhx_engine* e, int k, const char* expr, const char* const
   if (rtc_prepare_expr(expr, u.names, "bounds_total", &u.expr, &err) != 0)
     return fail(MHX_EINVAL, "%s", err.c_str());
   e->prior_expr[k] = u;
+  e->problem_dirty = true;
+  return MHX_OK;
+}
+
+int mhx_set_likelihood_expr(mhx_engine* e, int k, const char* expr) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  if (k < 0 || k >= e->P.K) return fail(MHX_EINVAL, "function index %d out of range", k);
+  if (!expr || !*expr) return fail(MHX_EINVAL, "likelihood expression is empty");
+  std::string out, err;
+  if (rtc_prepare_expr(expr, std::vector<std::string>(), "y model error", &out, &err) != 0)
+    return fail(MHX_EINVAL, "%s", err.c_str());
+  e->lik_expr[k] = out;
   e->problem_dirty = true;
   return MHX_OK;
 }

@@ -116,6 +116,14 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
           acc0 = acc0 + (t0 > -5000.0 ? t0 : -5000.0);  // (max -5000d0 term) M:426
           acc1 = acc1 + (t1 > -5000.0 ? t1 : -5000.0);
           // pads carry c = 0, w = 0 -> max(-5000, 0) = 0
+        } else if constexpr (LIK == MHX_LIK_EXPR) {
+          // (funcall log-liklihood-function y (apply fn x params) stddev) M:415: the tiles hold
+          // y and sigma as given; pads masked
+          const double t0 = Model::lik_term(ya, m0, wa);
+          const double t1 = Model::lik_term(yb, m1, wb);
+          const int i0 = k * kWave + l;
+          acc0 = acc0 + ((gbase + i0) < f.n ? t0 : 0.0);
+          acc1 = acc1 + ((gbase + i0 + kWave) < f.n ? t1 : 0.0);
         } else {
           // (- (* k (log lambda)) lambda ...) M:383; pads masked (no neutral pad exists)
           const double t0 = __builtin_fma(ya, mlog(m0), -m0);
@@ -138,7 +146,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
 template <int LIK>
 __device__ __forceinline__ double finish_lik(const FnDesc& f, double s) {
   if (LIK == MHX_LIK_NORMAL) return __builtin_fma(-0.5, s, f.lik_const);
-  if (LIK == MHX_LIK_NORMAL_CUTOFF) return s;
+  if (LIK == MHX_LIK_NORMAL_CUTOFF || LIK == MHX_LIK_EXPR) return s;
   return s + f.lik_const;
 }
 
@@ -179,6 +187,13 @@ struct GenericSpec {
       default:
         return finish_lik<MHX_LIK_POISSON>(f, sweep<Model, MHX_LIK_POISSON>(f, prep, active, lds));
     }
+  }
+  // one model with ONE likelihood: what run-time compiled problems use (mhx_rtc.cpp knows both)
+  template <class Model, int LIK, class PF>
+  static __device__ __forceinline__ double one_lik(const FnDesc& f, PF pf, bool active,
+                                                   GroupLds& lds) {
+    typename Model::Prep prep = Model::prepare(pf, f);
+    return finish_lik<LIK>(f, sweep<Model, LIK>(f, prep, active, lds));
   }
   template <class Model, class PF>
   static __device__ __forceinline__ double by_lik_dyn(const FnDesc& f, PF pf, bool active,

@@ -68,6 +68,12 @@ static const char* kFunctions[] = {"exp", "log", "sqrt", "sin", "cos", "tan", "a
 int rtc_prepare_expr(const std::string& expr, const std::vector<std::string>& names,
                      const char* extra, std::string* out, std::string* err) {
   std::set<std::string> params(names.begin(), names.end());
+  std::set<std::string> extras;
+  if (extra) {
+    std::istringstream is(extra);
+    std::string w;
+    while (is >> w) extras.insert(w);
+  }
   std::set<std::string> funcs;
   for (int i = 0; kFunctions[i]; ++i) funcs.insert(kFunctions[i]);
   std::string o;
@@ -86,7 +92,7 @@ int rtc_prepare_expr(const std::string& expr, const std::vector<std::string>& na
       size_t j = i;
       while (j < n && (isalnum((unsigned char)expr[j]) || expr[j] == '_')) ++j;
       const std::string id = expr.substr(i, j - i);
-      if (extra && id == extra) {
+      if (extras.count(id)) {
         o += id;
       } else if (params.count(id)) {
         o += "p_" + id;
@@ -95,6 +101,8 @@ int rtc_prepare_expr(const std::string& expr, const std::vector<std::string>& na
         else if (id == "min") o += "mhx_ux_min";
         else if (id == "max") o += "mhx_ux_max";
         else if (id == "ipow") o += "mhx_ux_ipow";
+        else if (id == "exp") o += "mhx_ux_exp";
+        else if (id == "log") o += "mhx_ux_log";
         else o += id;
       } else {
         *err = "unknown identifier '" + id + "' in expression";
@@ -149,7 +157,8 @@ int rtc_prepare_expr(const std::string& expr, const std::vector<std::string>& na
 
 // ---- source generation --------------------------------------------------------------------------
 static std::string generate(const std::vector<UserExpr>& models,
-                            const std::vector<UserExpr>& priors) {
+                            const std::vector<UserExpr>& priors, bool builtin_fallback,
+                            int min_waves) {
   std::ostringstream s;
   s << "#include \"mhx_kernels.hpp\"\n"
        "namespace mhx {\n"
@@ -161,6 +170,14 @@ static std::string generate(const std::vector<UserExpr>& models,
        "  int nextn = power >> 1; double total = (power & 1) ? base : 1.0;\n"
        "  while (nextn != 0) { base = base * base; if (nextn & 1) total = base * total; nextn >>= 1; }\n"
        "  return neg ? 1.0 / total : total;\n}\n";
+  // exp / log: the engine's own < 1 ulp routines (20 and 42 VALU instructions against ocml's
+  // 37 and 93); MHX_EXPR_OCML_MATH=1 selects ocml's.  (log x) of x <= 0 is an error in the
+  // reference; here it is a NaN, which marks the chain as trapped.
+  const bool ocml = getenv("MHX_EXPR_OCML_MATH") && atoi(getenv("MHX_EXPR_OCML_MATH")) != 0;
+  s << "__device__ __forceinline__ double mhx_ux_exp(double a) { return "
+    << (ocml ? "exp(a)" : "gexp(a)") << "; }\n"
+    << "__device__ __forceinline__ double mhx_ux_log(double a) { return "
+    << (ocml ? "(a > 0.0 ? log(a) : __builtin_nan(\"\"))" : "mlog(a)") << "; }\n";
   // Divisions by expressions that do not depend on x (1/w, 1/tau ...) are loop invariant; with
   // reciprocal math the compiler forms the reciprocal once per step instead of dividing per
   // data point (<= 1 ulp per quotient, inside the stated tolerance).  MHX_EXPR_EXACT_DIV=1
@@ -181,18 +198,34 @@ static std::string generate(const std::vector<UserExpr>& models,
     for (int j = 0; j < np; ++j)
       s << "    const double p_" << u.names[j] << " = q.p[" << j << "]; (void)p_" << u.names[j]
         << ";\n";
-    s << "    return (double)(" << u.expr << ");\n  }\n};\n";
+    s << "    return (double)(" << u.expr << ");\n  }\n";
+    if (!u.lik_expr.empty())
+      s << "  static __device__ __forceinline__ double lik_term(double y, double model, double error) {\n"
+        << "    (void)y; (void)model; (void)error;\n"
+        << "    return (double)(" << u.lik_expr << ");\n  }\n";
+    s << "};\n";
   }
   s << "struct UserSpec {\n"
        "  template <class PF>\n"
        "  static __device__ __forceinline__ double loglik(const FnDesc& f, PF pf, bool active,\n"
        "                                                  GroupLds& lds, double* scratch) {\n"
        "    switch (f.user_slot) {\n";
-  for (size_t m = 0; m < models.size(); ++m)
-    s << "      case " << m << ": return GenericSpec::by_lik<UserModel" << m
-      << ">(f, pf, active, lds);\n";
-  s << "      default: return GenericSpec::loglik(f, pf, active, lds, scratch);\n"
-       "    }\n  }\n"
+  // a slot belongs to one function, whose likelihood is known now: only that sweep is compiled
+  static const char* kLikName[] = {"MHX_LIK_NORMAL", "MHX_LIK_NORMAL_CUTOFF", "MHX_LIK_POISSON",
+                                   "MHX_LIK_EXPR"};
+  for (size_t m = 0; m < models.size(); ++m) {
+    const int lik = models[m].lik;
+    if (lik >= 0 && lik <= 3)
+      s << "      case " << m << ": return GenericSpec::one_lik<UserModel" << m << ", "
+        << kLikName[lik] << ">(f, pf, active, lds);\n";
+    else
+      s << "      case " << m << ": return GenericSpec::by_lik<UserModel" << m
+        << ">(f, pf, active, lds);\n";
+  }
+  s << (builtin_fallback
+            ? "      default: return GenericSpec::loglik(f, pf, active, lds, scratch);\n"
+            : "      default: (void)scratch; return 0.0;  // every function has a slot\n")
+    << "    }\n  }\n"
        "  static __device__ __forceinline__ double logprior(const FnDesc& f, const double* th,\n"
        "                                                    double bounds_total) {\n"
        "    switch (f.prior_slot) {\n";
@@ -221,21 +254,29 @@ static std::string generate(const std::vector<UserExpr>& models,
        "    const ProblemDesc* P, ChainState S, const double* L, int per_chain_l, const double* z,\n"
        "    const double* u, const double* T, unsigned char* accepted) {\n"
        "  k_step_injected_body<UserSpec>(P, S, L, per_chain_l, z, u, T, accepted);\n}\n"
-       "extern \"C\" __global__ __launch_bounds__(512, 2) void mhx_user_adaptive(\n"
+       "extern \"C\" __global__ __launch_bounds__(512, "
+    << min_waves
+    << ") void mhx_user_adaptive(\n"
        "    const ProblemDesc* P, ChainState S, RunDesc R, int64_t max_iters, int plain) {\n"
        "  k_adaptive_body<UserSpec>(P, S, R, max_iters, plain);\n}\n";
   return s.str();
 }
 
-int rtc_build(const std::vector<UserExpr>& models, const std::vector<UserExpr>& priors, int d,
-              UserProgram* prog, std::string* err) {
-  (void)d;
+static int build_once(const std::vector<UserExpr>& models, const std::vector<UserExpr>& priors,
+                      bool builtin_fallback, int min_waves, UserProgram* prog,
+                      std::string* err) {
   Hiprtc& r = rtc();
   if (!r.ok) {
     *err = "libhiprtc.so could not be loaded: expression models need ROCm's hiprtc";
     return -1;
   }
-  prog->source = generate(models, priors);
+  prog->source = generate(models, priors, builtin_fallback, min_waves);
+  if (const char* dump = getenv("MHX_RTC_DUMP")) {  // the generated translation unit, for study
+    if (FILE* fp = fopen(dump, "w")) {
+      fputs(prog->source.c_str(), fp);
+      fclose(fp);
+    }
+  }
   const char* hdr_src[] = {kSrc_mhx_kernels_hpp, kSrc_mhx_device_hpp, kSrc_mhx_types_hpp,
                            kSrc_mhx_h};
   const char* hdr_name[] = {"mhx_kernels.hpp", "mhx_device.hpp", "mhx_types.hpp",
@@ -288,6 +329,27 @@ int rtc_build(const std::vector<UserExpr>& models, const std::vector<UserExpr>& 
     }
   }
   return 0;
+}
+
+// The stepping kernel is first built for 4 waves per SIMD (<= 128 VGPRs: two workgroups per
+// CU, which is what hides the latency of the dependent fp64 chains).  If the expression is too
+// big for that register budget - the kernel spills into scratch beyond the few bytes the
+// controller's own code uses - it is rebuilt for 2 waves per SIMD (256 VGPRs).
+// MHX_RTC_MIN_WAVES=2|4 pins the choice.
+int rtc_build(const std::vector<UserExpr>& models, const std::vector<UserExpr>& priors,
+              bool builtin_fallback, UserProgram* prog, std::string* err) {
+  int pinned = 0;
+  if (const char* s = getenv("MHX_RTC_MIN_WAVES")) pinned = atoi(s);
+  if (pinned == 2 || pinned == 4)
+    return build_once(models, priors, builtin_fallback, pinned, prog, err);
+  int rc = build_once(models, priors, builtin_fallback, 4, prog, err);
+  if (rc != 0) return rc;
+  int scratch = 0;
+  if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, prog->f_adaptive) !=
+          hipSuccess ||
+      scratch <= 128)
+    return 0;
+  return build_once(models, priors, builtin_fallback, 2, prog, err);
 }
 
 static inline unsigned grid_for(int64_t n) {

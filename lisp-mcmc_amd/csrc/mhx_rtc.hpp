@@ -19,6 +19,8 @@ struct UserExpr {
   std::string expr;                // validated, identifiers already rewritten
   std::vector<std::string> names;  // as given by the caller
   std::vector<int> index;
+  int lik = -1;          // models: the function's likelihood kind (-1: dispatch at run time)
+  std::string lik_expr;  // models with MHX_LIK_EXPR: the per-point term over y, model, error
 };
 
 struct UserProgram {
@@ -30,13 +32,16 @@ struct UserProgram {
 
 // Checks `expr` against the expression grammar of include/mhx.h and rewrites it for splicing:
 // parameter identifiers -> p_<name>, integer literals -> doubles, abs/min/max -> device forms.
-// extra: additional identifiers allowed as they are ("x" or "bounds_total").
+// extra: additional identifiers allowed as they are, separated by blanks ("x", "bounds_total",
+// "y model error").
 int rtc_prepare_expr(const std::string& expr, const std::vector<std::string>& names,
                      const char* extra, std::string* out, std::string* err);
 
-// models[slot] / priors[slot] -> compiled module.  Returns 0 or fills *err.
-int rtc_build(const std::vector<UserExpr>& models, const std::vector<UserExpr>& priors, int d,
-              UserProgram* prog, std::string* err);
+// models[slot] / priors[slot] -> compiled module.  builtin_fallback: the problem also has
+// functions with ahead-of-time models, so the generic dispatcher must be part of the kernels.
+// Returns 0 or fills *err.
+int rtc_build(const std::vector<UserExpr>& models, const std::vector<UserExpr>& priors,
+              bool builtin_fallback, UserProgram* prog, std::string* err);
 
 hipError_t rtc_launch_logpost(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                               const double* theta, int64_t n, double* out, double* parts);

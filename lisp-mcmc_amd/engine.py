@@ -54,6 +54,11 @@ class Engine:
         capi.check(capi.lib().mhx_set_prior_expr(self._h, k, (expr or "").encode(),
                                                  self._names(names), ixp, len(ix)))
 
+    def set_likelihood_expr(self, k, expr):
+        """per-point log-likelihood term of function k over y, model, error (dataset k must use
+        LIK_EXPR, function k an expression model)"""
+        capi.check(capi.lib().mhx_set_likelihood_expr(self._h, k, expr.encode()))
+
     def set_dataset(self, k, x, y, sigma=None, likelihood=capi.LIK_NORMAL):
         xa, xp = capi.as_f64(x)
         ya, yp = capi.as_f64(y)

@@ -23,6 +23,7 @@ library, or without a gfx950 device, walker-create signals MHX-ERROR."
 (defconstant +lik-normal+ 0)
 (defconstant +lik-normal-cutoff+ 1)
 (defconstant +lik-poisson+ 2)
+(defconstant +lik-expr+ 3)
 (defconstant +chain-running+ 0)
 (defconstant +chain-done+ 1)
 (defconstant +chain-fp-trap+ 2)
@@ -63,7 +64,11 @@ library, or without a gfx950 device, walker-create signals MHX-ERROR."
   (e :pointer) (k :int) (expr :string) (param-names :pointer) (param-index :pointer) (n-index :int))
 (cffi:defcfun ("mhx_set_prior_expr" %mhx-set-prior-expr) :int
   (e :pointer) (k :int) (expr :string) (names :pointer) (index :pointer) (n :int))
+(cffi:defcfun ("mhx_set_likelihood_expr" %mhx-set-likelihood-expr) :int
+  (e :pointer) (k :int) (expr :string))
 (cffi:defcfun ("mhx_walker_modify" %mhx-walker-modify) :int (e :pointer) (action :int) (n :int64))
+(cffi:defcfun ("mhx_set_history" %mhx-set-history) :int
+  (e :pointer) (chain :int64) (prob :pointer) (theta :pointer) (n :int))
 (cffi:defcfun ("mhx_get_pooled" %mhx-get-pooled) :int
   (e :pointer) (stats :pointer) (l-pool :pointer) (valid :pointer) (refreshes :pointer))
 (cffi:defcfun ("mhx_init_chains" %mhx-init-chains) :int

@@ -60,9 +60,18 @@
                                  (format nil "(1.0 / ~a)" (tr (first a)))))
                           (1+ (format nil "(~a + 1.0)" (tr (first a))))
                           (1- (format nil "(~a - 1.0)" (tr (first a))))
-                          (expt (if (and (integerp (second a)) (<= (abs (second a)) 64))
-                                    (format nil "ipow(~a, ~d)" (tr (first a)) (second a))
-                                    (format nil "pow(~a, ~a)" (tr (first a)) (tr (second a)))))
+                          ;; an integer exponent is repeated multiplication (intexp order); a
+                          ;; float literal with an integral value - the (expt q 2d0) of
+                          ;; mcmc-fitting.lisp:377 - is libm's pow there, within an ulp of the
+                          ;; product, and the product is what the device forms
+                          (expt (let ((p (second a)))
+                                  (cond ((and (integerp p) (<= (abs p) 64))
+                                         (format nil "ipow(~a, ~d)" (tr (first a)) p))
+                                        ((and (floatp p) (= p (fround p)) (<= (abs p) 64))
+                                         (format nil "ipow(~a, ~d)" (tr (first a)) (round p)))
+                                        ((and (floatp p) (= p 0.5))
+                                         (format nil "sqrt(~a)" (tr (first a))))
+                                        (t (format nil "pow(~a, ~a)" (tr (first a)) (tr p))))))
                           ((max min)
                            (reduce (lambda (acc v) (format nil "~(~a~)(~a, ~a)" op acc (tr v)))
                                    (cdr a) :initial-value (tr (first a))))
@@ -75,6 +84,13 @@
                                       (format nil "~a(~a)" fn (tr (first a))))
                                      ((and (eq op 'log) (= (length a) 2))
                                       (format nil "(log(~a) / log(~a))" (tr (first a)) (tr (second a))))
+                                     ;; (log-normal x mu sigma), mcmc-fitting.lisp:372-377,
+                                     ;; expanded; matched by name, whatever package it was read in
+                                     ((and (symbolp op) (string= (symbol-name op) "LOG-NORMAL")
+                                           (= (length a) 3))
+                                      (destructuring-bind (x mu sigma) a
+                                        (tr `(+ (* -1/2 (log (* 2 pi))) (* -1 (log ,sigma))
+                                                (* -1/2 (expt (/ (- ,x ,mu) ,sigma) 2d0))))))
                                      (t (error 'mhx-error :code -5
                                                           :message (format nil "operator ~s is not supported in a device expression" op)))))))))))
            (test (f)
@@ -117,6 +133,26 @@
                   :keys (mapcar (lambda (k) (intern (symbol-name k) :keyword)) keys)
                   :shape nil
                   :expr (form->c (first body) (list (cons (first lambda-list) "x")))))))
+
+(defun create-log-liklihood-function-amd (lambda-form)
+  "The reference's create-log-liklihood-function (mcmc-fitting.lisp:402-416) for a QUOTED
+3-argument closure; evaluates to a :log-liklihood DESIGNATOR:
+(create-log-liklihood-function-amd
+  '(lambda (y model error) (declare (ignore error)) (- (* y (log model)) model)))
+The log-likelihood is the sum of its values over the points.  ERROR is the point's sigma, as
+the reference's docstring defines it.  The walker's :function must be an expr-model."
+  (destructuring-bind (lambda-sym lambda-list &rest body) lambda-form
+    (declare (ignore lambda-sym))
+    (let ((body (remove-if (lambda (b) (and (consp b) (eq (car b) 'declare))) body)))
+      (unless (and (= (length lambda-list) 3) (every #'symbolp lambda-list))
+        (error 'mhx-error :code -5
+                          :message "the function must accept 3 arguments: y, model, error"))
+      (unless (= (length body) 1)
+        (error 'mhx-error :code -5 :message "the lambda body must be one expression"))
+      (make-likelihood-spec
+       :expr (form->c (first body) (list (cons (first lambda-list) "y")
+                                         (cons (second lambda-list) "model")
+                                         (cons (third lambda-list) "error")))))))
 
 (defmacro prior-bounds-let-amd ((&rest keys-low-high) &body body)
   "Same shape as the reference's prior-bounds-let (mcmc-fitting.lisp:346-369), but evaluates to a

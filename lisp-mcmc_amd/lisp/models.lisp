@@ -48,9 +48,14 @@
     (log-liklihood-normal-cutoff . 1) (log-liklihood-poisson . 2)
     (:normal . 0) (:normal-cutoff . 1) (:poisson . 2)))
 
+;;; what create-log-liklihood-function-amd returns (expr.lisp): the closure's body as C text
+(defstruct likelihood-spec
+  (expr "" :type string))
+
 (defun likelihood-id (designator)
   (let ((d (if (null designator) 'log-liklihood-normal designator)))
-    (or (cdr (assoc d *likelihood-ids*))
+    (or (and (likelihood-spec-p d) 3)
+        (cdr (assoc d *likelihood-ids*))
         (error 'mhx-error :code -5
                           :message (format nil "unsupported :log-liklihood ~s (a closure cannot ~
                                                 cross to the GPU; see INTEGRATION.md)" d)))))

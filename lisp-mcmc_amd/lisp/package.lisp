@@ -25,5 +25,6 @@
    #:lorder-mixed-bg-model #:exp-decay-model #:sinusoid-model #:pvoigt2-model
    ;; arbitrary closures / prior bodies, compiled at run time (expr.lisp)
    #:expr-model #:prior-bounds-let-amd #:form->c #:bounds-total
+   #:create-log-liklihood-function-amd #:log-normal
    ;; engine-level extras
    #:walker-n-chains #:walker-chain-status #:mhx-error #:mhx-error-code #:mhx-error-message))

@@ -150,6 +150,9 @@ set that steps as one batch."
                    (fill-doubles cs sg)
                    (with-c-call
                      (check (%mhx-set-dataset engine k cx cy cs n (likelihood-id lik)))))
+                 (when (likelihood-spec-p lik)
+                   (with-c-call
+                     (check (%mhx-set-likelihood-expr engine k (likelihood-spec-expr lik)))))
                  (let ((bounds (cond ((null pri) nil)
                                      ((eq pri 'log-prior-flat) nil)
                                      ((eq pri #'log-prior-flat) nil)

@@ -133,7 +133,20 @@ def to_c(form, rename=None):
             # order), a float exponent goes through pow like (expt q 2d0) of M:377
             if isinstance(a[1], str) and re.match(r"^[+-]?\d+$", a[1]) and abs(int(a[1])) <= 64:
                 return "ipow(" + go(a[0]) + ", " + str(int(a[1])) + ")"
+            # a float literal with an integral value ((expt q 2d0), M:377) is libm's pow there,
+            # which is within an ulp of the product; the product is what the device forms
+            # (ocml's pow costs ~220 instructions per point)
+            lit = number(a[1]) if isinstance(a[1], str) else None
+            if lit is not None and "/" not in lit:
+                v = float(lit)
+                if v == int(v) and abs(v) <= 64:
+                    return "ipow(" + go(a[0]) + ", " + str(int(v)) + ")"
+                if v == 0.5:
+                    return "sqrt(" + go(a[0]) + ")"
             return "pow(" + go(a[0]) + ", " + go(a[1]) + ")"
+        if op == "log-normal" and len(a) == 3:  # (log-normal x mu sigma) M:372-377, expanded
+            return go(["+", ["*", "-1/2", ["log", ["*", "2", "pi"]]], ["*", "-1", ["log", a[2]]],
+                       ["*", "-1/2", ["expt", ["/", ["-", a[0], a[1]], a[2]], "2d0"]]])
         if op in _FUN1 and len(a) == 1:
             return _FUN1[op] + "(" + go(a[0]) + ")"
         if op == "log" and len(a) == 2:
@@ -213,6 +226,25 @@ def lambda_to_expr(text):
         else:
             out.append(k)
     return out, cexpr
+
+
+def likelihood_lambda_to_expr(text):
+    """The closure given to create-log-liklihood-function (M:402-416),
+    '(lambda (y model error) (declare (ignore error)) body)' -> C expression over y, model, error
+    (the three arguments may carry any names)."""
+    form = parse(text)
+    if isinstance(form, list) and len(form) == 2 and form[0] in ("function", "quote"):
+        form = form[1]
+    if not (isinstance(form, list) and len(form) >= 3 and isinstance(form[0], str)
+            and form[0].lower() == "lambda"):
+        raise SexprError("expected (lambda (y model error) body)")
+    ll = form[1]
+    if not (isinstance(ll, list) and len(ll) == 3 and all(isinstance(a, str) for a in ll)):
+        raise SexprError("the function must accept 3 arguments: y, model, error (M:403)")
+    body = [b for b in form[2:] if not (isinstance(b, list) and b and b[0] == "declare")]
+    if len(body) != 1:
+        raise SexprError("the lambda body must be one expression")
+    return to_c(body[0], {ll[0].lower(): "y", ll[1].lower(): "model", ll[2].lower(): "error"})
 
 
 def prior_body_to_expr(text):

@@ -73,6 +73,25 @@ def prior_bounds(bounds, body=None):
     return PriorBounds(bounds, body)
 
 
+class LikelihoodExpr:
+    """What (create-log-liklihood-function #'(lambda (y model error) ...)) returns, M:402-416"""
+
+    def __init__(self, text):
+        from . import sexpr
+        self.text = text
+        self.expr = sexpr.likelihood_lambda_to_expr(text)
+
+
+def create_log_liklihood_function(text):
+    """(create-log-liklihood-function log-liklihood-function) M:402-416 as a :log-liklihood
+    designator.  TEXT is the Lisp text of the 3-argument closure, e.g.
+    '(lambda (y model error) (declare (ignore error)) (- (* y (log model)) model))'; the
+    log-likelihood is the sum of its values over the points.  `error` is the point's sigma (the
+    docstring's meaning; the reference's code hands every call the whole stddev list).  The
+    function the walker fits must then be an expression model (models.lisp / models.expr)."""
+    return LikelihoodExpr(text)
+
+
 log_prior_flat = None  # (log-prior-flat params data) => 0d0, M:340-343
 
 
@@ -229,11 +248,15 @@ def walker_create(function=None, data=None, params=None, data_error=None, log_li
         else:
             eng.set_function(k, f.model_id, f.shape, [keys.index(q) for q in f.keys])
         lk = liks[k]
-        if isinstance(lk, str):
-            lk = lk.lstrip("#':").lower()
-        if lk not in _LIKS:
-            raise capi.MhxError(capi.EUNSUPPORTED, "unknown :log-liklihood %r" % (liks[k],))
-        eng.set_dataset(k, dsets[k][0], dsets[k][1], sig[k], _LIKS[lk])
+        if isinstance(lk, LikelihoodExpr):
+            eng.set_dataset(k, dsets[k][0], dsets[k][1], sig[k], capi.LIK_EXPR)
+            eng.set_likelihood_expr(k, lk.expr)
+        else:
+            if isinstance(lk, str):
+                lk = lk.lstrip("#':").lower()
+            if lk not in _LIKS:
+                raise capi.MhxError(capi.EUNSUPPORTED, "unknown :log-liklihood %r" % (liks[k],))
+            eng.set_dataset(k, dsets[k][0], dsets[k][1], sig[k], _LIKS[lk])
         pr = pris[k]
         if pr is None:
             eng.set_bounds(k, [], [], [])

@@ -50,3 +50,37 @@ def test_product_never_touches_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".inc", ".h", ".lisp", ".asd")):
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "oraclelib" not in txt and "mhx_oracle" not in txt and "orc_" not in txt, f
+
+
+def test_lisp_shim_binds_every_header_symbol():
+    """the CFFI shim (never executed here: no Lisp in the image) at least declares a defcfun for
+    every entry point and its files are paren-balanced"""
+    d = os.path.join(ROOT, "lisp-mcmc_amd", "lisp")
+    bound = set(re.findall(r'defcfun\s+\(?"(mhx_[a-z0-9_]+)"', open(os.path.join(d, "bindings.lisp")).read()))
+    missing = [n for n in header_functions() if n not in bound]
+    assert not missing, missing
+    for f in sorted(os.listdir(d)):
+        if not f.endswith(".lisp"):
+            continue
+        s, depth, i = open(os.path.join(d, f)).read(), 0, 0
+        while i < len(s):
+            c = s[i]
+            if c == ";":
+                while i < len(s) and s[i] != "\n":
+                    i += 1
+                continue
+            if c == '"':
+                i += 1
+                while s[i] != '"':
+                    i += 2 if s[i] == "\\" else 1
+            elif c == "#" and s[i + 1] == "\\":
+                i += 2
+            elif c == "#" and s[i + 1] == "|":
+                i = s.index("|#", i) + 1
+            elif c == "(":
+                depth += 1
+            elif c == ")":
+                depth -= 1
+                assert depth >= 0, (f, s[:i].count("\n") + 1)
+            i += 1
+        assert depth == 0, f

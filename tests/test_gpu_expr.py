@@ -165,3 +165,92 @@ def test_expression_errors(mhx):
     v = e.logpost([[0.0, 3.0]])[0]
     assert v == pytest.approx(2 * (-0.5 * np.log(2 * np.pi)), abs=1e-15)
     e.close()
+
+
+# ---- create-log-liklihood-function (M:402-416): the per-point likelihood as a closure --------
+def _lik_walker(mhx, lik_text, model_text, x, y, sig, params, n_chains=1, seed=3):
+    return mhx.walker_create(function=mhx.models.lisp(model_text), data=[x, y], params=params,
+                             data_error=sig, n_chains=n_chains, seed=seed,
+                             log_liklihood=mhx.create_log_liklihood_function(lik_text))
+
+
+def test_custom_likelihood_equals_builtin_normal(mhx):
+    """(log-normal y model error) through create-log-liklihood-function is log-liklihood-normal"""
+    rng = np.random.default_rng(5)
+    n = 2500  # three tiles, the last one ragged
+    x = np.linspace(-2, 3, n)
+    sig = rng.uniform(0.1, 0.4, n)
+    y = 0.7 - 0.4 * x + 0.2 * x * x + sig * rng.standard_normal(n)
+    model = "(lambda (x &key a b c &allow-other-keys) (+ a (* b x) (* c (expt x 2))))"
+    params = [":a", 0.5, ":b", -0.3, ":c", 0.25]
+    w0 = mhx.walker_create(function=mhx.models.lisp(model), data=[x, y], params=params, data_error=sig)
+    w1 = _lik_walker(mhx, "(lambda (y model error) (log-normal y model error))", model, x, y, sig, params)
+    m = 0.5 - 0.3 * x + 0.25 * x * x
+    terms = -0.5 * np.log(2 * np.pi) - np.log(sig) - 0.5 * ((y - m) / sig) ** 2
+    ref = float(np.sum(terms))
+    tol = REL * float(np.sum(np.abs(terms)))
+    assert abs(w1.last_step().prob - ref) <= tol
+    assert abs(w1.last_step().prob - w0.last_step().prob) <= tol
+
+
+def test_custom_likelihood_poisson_closure(mhx):
+    """the README-style Poisson closure that ignores `error`; its sum differs from log-poisson's
+    only by the parameter-independent sum of log k!"""
+    rng = np.random.default_rng(6)
+    n = 1500
+    x = np.linspace(0, 1, n)
+    lam = 30 + 80 * np.exp(-((x - 0.4) / 0.1) ** 2)
+    y = rng.poisson(lam).astype(float)
+    model = "(lambda (x &key bg a mu w &allow-other-keys) (+ bg (* a (exp (- (expt (/ (- x mu) w) 2))))))"
+    params = [":bg", 28.0, ":a", 85.0, ":mu", 0.41, ":w", 0.105]
+    lik = "(lambda (y model error) (declare (ignore error)) (- (* y (log model)) model))"
+    w = _lik_walker(mhx, lik, model, x, y, None, params, n_chains=4)
+    m = 28.0 + 85.0 * np.exp(-((x - 0.41) / 0.105) ** 2)
+    terms = y * np.log(m) - m
+    assert abs(w.last_step().prob - float(terms.sum())) <= REL * float(np.abs(terms).sum())
+    wp = mhx.walker_create(function=mhx.models.lisp(model), data=[x, y], params=params,
+                           log_liklihood="poisson", n_chains=4, seed=3)
+    # same seed, same proposals; the two posteriors differ by a constant, so the walks coincide
+    # a Poisson rate must stay positive ((log model) of a negative model is an error in the
+    # reference as well): start from a small :l-matrix rather than diag(theta)
+    l0 = np.diag(0.002 * np.array(params[1::2]))
+    for ww in (w, wp):
+        mhx.walker_adaptive_steps_full(ww, n=1200, temperature=10, auto=":prob-settle", l_matrix=l0)
+    a = np.array(list(mhx.walker_get(w, get=":most-likely-params").values()))
+    b = np.array(list(mhx.walker_get(wp, get=":most-likely-params").values()))
+    assert np.allclose(a, b, rtol=1e-9)
+    assert abs(a[2] - 0.4) < 0.02 and abs(a[1] - 80) < 15
+
+
+def test_custom_likelihood_uses_error_and_branches(mhx):
+    """a robust (Huber-like) term: error is the point's sigma, `if` picks the branch per point"""
+    rng = np.random.default_rng(7)
+    n = 700
+    x = np.linspace(0, 5, n)
+    sig = rng.uniform(0.2, 0.5, n)
+    y = 1.0 + 2.0 * x + sig * rng.standard_normal(n)
+    y[::50] += 25.0  # outliers
+    model = "(lambda (x &key m b &allow-other-keys) (+ b (* m x)))"
+    lik = ("(lambda (y model error) (if (< (abs (/ (- y model) error)) 2)"
+           " (* -1/2 (expt (/ (- y model) error) 2))"
+           " (- 2 (* 2 (abs (/ (- y model) error))))))")
+    w = _lik_walker(mhx, lik, model, x, y, sig, [":b", 0.8, ":m", 2.1])
+    r = np.abs((y - (0.8 + 2.1 * x)) / sig)
+    terms = np.where(r < 2, -0.5 * r * r, 2 - 2 * r)
+    assert abs(w.last_step().prob - float(terms.sum())) <= REL * float(np.abs(terms).sum())
+    mhx.walker_adaptive_steps(w, 4000)
+    ml = mhx.walker_get(w, get=":most-likely-params")
+    assert abs(ml["b"] - 1.0) < 0.15 and abs(ml["m"] - 2.0) < 0.05  # the outliers do not pull it
+
+
+def test_custom_likelihood_errors(mhx):
+    x, y = [0.0, 1.0, 2.0], [1.0, 2.0, 3.0]
+    lik = mhx.create_log_liklihood_function("(lambda (y model error) (- (abs (- y model))))")
+    with pytest.raises(mhx.MhxError, match="expression model"):
+        mhx.walker_create(function=mhx.models.line("b", "m"), data=[x, y], params=[":b", 0, ":m", 1],
+                          log_liklihood=lik)
+    with pytest.raises(mhx.MhxError, match="unknown identifier"):
+        mhx.walker_create(function=mhx.models.lisp("(lambda (x &key m b &allow-other-keys) (+ b (* m x)))"),
+                          data=[x, y], params=[":b", 0, ":m", 1],
+                          log_liklihood=mhx.create_log_liklihood_function(
+                              "(lambda (y model error) (* scale (- y model)))"))

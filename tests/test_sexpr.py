@@ -98,6 +98,34 @@ def test_prior_body_translation(sx):
         assert got == ref
 
 
+def test_likelihood_closure_translation(sx):
+    """create-log-liklihood-function's 3-argument closures (M:402-416), incl. log-normal (M:372)"""
+    cases = [
+        ("(lambda (y model error) (declare (ignore error)) (- (* y (log model)) model))", None),
+        ("(lambda (yy mm ee) (log-normal yy mm ee))", "lognormal"),
+        ("(lambda (y model error) (if (< (abs (/ (- y model) error)) 2) (* -1/2 (expt (/ (- y model) error) 2d0))"
+         " (- 2 (* 2 (abs (/ (- y model) error))))))", None),
+    ]
+    rng = np.random.default_rng(1)
+    for text, kind in cases:
+        cexpr = sx.likelihood_lambda_to_expr(text)
+        assert "pow(" not in cexpr.replace("ipow(", "")      # (expt q 2d0) is a product
+        fn = compile_c([cexpr], ["y", "model", "error"])[0]
+        form = sx.parse(text)
+        argn = [a.lower() for a in form[1]]
+        for _ in range(20):
+            p = rng.uniform(0.5, 3.0, 3)
+            got = fn(0.0, p.ctypes.data_as(C.POINTER(C.c_double)), 0.0)
+            if kind == "lognormal":
+                ref = -0.5 * np.log(2 * np.pi) - np.log(p[2]) - 0.5 * ((p[0] - p[1]) / p[2]) ** 2
+            else:
+                body = [b for b in form[2:] if not (isinstance(b, list) and b[0] == "declare")][0]
+                ref = sexpr_eval.evaluate(body, dict(zip(argn, p)))
+            assert abs(got - ref) <= 4e-16 * max(1.0, abs(ref)), (text, p, got, ref)
+    with pytest.raises(sx.SexprError):
+        sx.likelihood_lambda_to_expr("(lambda (y model) (- y model))")
+
+
 def test_rejects_unsupported_forms(sx):
     with pytest.raises(sx.SexprError):
         sx.lambda_to_expr("(lambda (x &key a) (funcall a x))")
