@@ -111,3 +111,37 @@ def test_c2_full_batch_walks_like_small_batch_and_oracle(mhx, orc, c2):
     assert np.array_equal(shard.state()["theta"], sb["theta"][2048:2056])
     for e in (big, small, shard):
         e.close()
+
+
+def test_c5_per_gpu_share_65536_chains(mhx, orc, c2):
+    """BASELINE config 5 puts 524288 chains on 8 GPUs = 65536 per GPU.  One rank's share, taken
+    from the MIDDLE of the global id range (rank 3: ids 196608...), with the pooled-covariance
+    mode the multi-GPU bench uses: chains must coincide with an 8-chain engine owning the same
+    global ids, and every chain must have moved the same number of steps."""
+    C_, n_it, off = 65536, 12, 3 * 65536
+    rng = np.random.Generator(np.random.Philox(key=99))
+    th0 = c2.theta_star[None, :] * (1.0 + 0.01 * rng.standard_normal((C_, c2.d)))
+    big = c2.engine(mhx, C_, seed=21, chain_offset=off, adapt_mode=mhx.capi.ADAPT_POOLED)
+    big.init_chains(th0)
+    big.adaptive_begin(30000, 10.0, 1)
+    assert big.adaptive_advance(n_it) == C_
+    sb = big.state()
+    assert (sb["age"] == n_it + 1).all() and big.counters()[0] == C_ * n_it
+    assert np.isfinite(sb["logpost"]).all()
+    st, _ = big.chain_status()
+    assert (st == mhx.capi.CHAIN_RUNNING).all()
+    for lo in (0, 40000, C_ - 8):
+        small = c2.engine(mhx, 8, seed=21, chain_offset=off + lo, adapt_mode=mhx.capi.ADAPT_POOLED)
+        small.init_chains(th0[lo:lo + 8])
+        small.adaptive_begin(30000, 10.0, 1)
+        small.adaptive_advance(n_it)
+        ss = small.state()
+        assert np.array_equal(sb["theta"][lo:lo + 8], ss["theta"]), lo
+        assert np.array_equal(sb["logpost"][lo:lo + 8], ss["logpost"]), lo
+        small.close()
+    op = c2.oracle(orc)
+    w = orc.Walker(op, th0[40001])
+    w.adaptive_begin(30000, 10.0, 1, seed=21, chain_id=off + 40001)
+    w.adaptive_advance(n_it)
+    assert np.array_equal(sb["theta"][40001], w.last()[0])
+    big.close()
