@@ -191,22 +191,41 @@ __device__ __forceinline__ double mexp2(double s) {
 // c11 = kExp2C11, handed in from a VGPR the caller keeps alive across its loop: the first
 // Horner step reads two constants, and only one may come from the scalar file
 constexpr double kExp2C11 = 0x1.e9d3fe3952179p-32;
-__device__ __forceinline__ double mexp2_negsq(double t, double c11 = kExp2C11) {
-  const double MAGIC = 0x1.8p52;
-  const double kd = __builtin_fma(-t, t, MAGIC);
-  const double kf = kd - MAGIC;
+// The constants of mexp2_negsq, pinned to register files once per step by the caller: every
+// v_fma_f64 of the Horner chain may read ONE scalar operand, so c[0..9] and the magic number
+// live in SGPRs and c11 (which shares the first fma with c[0]) in a VGPR.  Left to itself the
+// compiler materialises the coefficients in VGPRs as soon as the loop body has branches and
+// then copies one into the accumulator before every v_fmac - twice the instructions.
+struct Exp2K {
+  double c11;    // VGPR
+  double c[10];  // SGPRs: the coefficients of f^10 ... f^1
+  double magic;  // SGPR
+  __device__ __forceinline__ void pin() {
+    constexpr double k[10] = {0x1.e6063f7217bc6p-28, 0x1.b524fae627834p-24, 0x1.62bfd47773353p-20,
+                              0x1.ffcbfc670dcd4p-17, 0x1.430913096fd9fp-13, 0x1.5d87fe78a5276p-10,
+                              0x1.3b2ab6fba1ddap-7,  0x1.c6b08d704a0c2p-5,  0x1.ebfbdff82c598p-3,
+                              0x1.62e42fefa39efp-1};
+    double v = kExp2C11;
+    asm volatile("" : "+v"(v));
+    c11 = v;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      double s = k[i];
+      asm volatile("" : "+s"(s));
+      c[i] = s;
+    }
+    double m = 0x1.8p52;
+    asm volatile("" : "+s"(m));
+    magic = m;
+  }
+};
+__device__ __forceinline__ double mexp2_negsq(double t, const Exp2K& K) {
+  const double kd = __builtin_fma(-t, t, K.magic);
+  const double kf = kd - K.magic;
   const double f = __builtin_fma(-t, t, -kf);
-  double p = c11;
-  p = __builtin_fma(p, f, 0x1.e6063f7217bc6p-28);
-  p = __builtin_fma(p, f, 0x1.b524fae627834p-24);
-  p = __builtin_fma(p, f, 0x1.62bfd47773353p-20);
-  p = __builtin_fma(p, f, 0x1.ffcbfc670dcd4p-17);
-  p = __builtin_fma(p, f, 0x1.430913096fd9fp-13);
-  p = __builtin_fma(p, f, 0x1.5d87fe78a5276p-10);
-  p = __builtin_fma(p, f, 0x1.3b2ab6fba1ddap-7);
-  p = __builtin_fma(p, f, 0x1.c6b08d704a0c2p-5);
-  p = __builtin_fma(p, f, 0x1.ebfbdff82c598p-3);
-  p = __builtin_fma(p, f, 0x1.62e42fefa39efp-1);
+  double p = K.c11;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) p = __builtin_fma(p, f, K.c[i]);
   p = __builtin_fma(p, f, 1.0);
   return ldexp(p, (int)__double_as_longlong(kd));  // low dword of 1.5*2^52 + k is k
 }
@@ -330,13 +349,58 @@ struct PeaksModel {
     double A[NPK], mu[NPK], iw[NPK];
     double cv[NPK];  // mu[] once more, pinned in VGPRs: t = fma(x, iw, c) may read only ONE
                      // scalar operand (constant bus), so c would be re-copied for every point
-    double c11;      // leading coefficient of the 2^f polynomial, pinned likewise
+    Exp2K K;         // the constants of the 2^f polynomial, pinned likewise
     bool fast;  // |t| < 46000 over the whole x range for every peak (uniform)
+    bool skip;  // tile-level skipping allowed this step (see tile_mask)
+    int thr[NPK];  // -(binary exponent of A_k) - 56
   };
+  // Tile-level skipping of Gaussian peaks, an EXACT transformation of the fast path.
+  // Over a tile whose x lie in [xlo, xhi], t_k = fma(x, iw_k, c_k) is monotone in x, so
+  // |t_k| >= tmin = min(|t_k(xlo)|, |t_k(xhi)|) when both ends have the same sign, hence
+  // k = rint(-t^2) <= kmin = rint(-tmin^2) (the same fma, monotone) and the peak's value
+  // e = ldexp(p, k) with p < 2 obeys e < 2^(kmin+1).  With 0 <= A_k < 2^ea that bounds the
+  // addend of f = fma(A_k, e, f) by 2^(ea+kmin+1).  The running f is >= the background over the
+  // tile, bmin = min(bg(xlo), bg(xhi)) (Horner fma, monotone for NBG <= 2; every earlier peak
+  // added a non-negative amount), and bmin >= 2^(ef-1).  A double g > 0 has no neighbour closer
+  // than g 2^-53, so an addend below g 2^-54 leaves fma(A, e, f) == f: the peak is a no-op for
+  // every point of the tile when  ea + kmin + 1 <= ef - 55.  Preconditions (else every peak is
+  // evaluated): fast path, 1 <= NBG <= 2, all A_k finite and >= 0, bmin > 0 and finite.
+  static constexpr bool kHasSkip = !LORENTZ && NBG >= 1 && NBG <= 2 && NPK <= 30;
+  static constexpr int kPeaks = NPK;
+  static __device__ __forceinline__ double bg_of(const Prep& p, double x) {
+    double f = p.bg[NBG > 0 ? NBG - 1 : 0];
+#pragma unroll
+    for (int j = NBG - 2; j >= 0; --j) f = __builtin_fma(f, x, p.bg[j]);
+    return f;
+  }
+  static __device__ __forceinline__ unsigned tile_mask(const Prep& p, double xlo, double xhi) {
+    constexpr unsigned all = (1u << NPK) - 1u;
+    const double blo = bg_of(p, xlo), bhi = bg_of(p, xhi);
+    const double bmin = blo < bhi ? blo : bhi;
+    const bool usable = p.skip && (bmin > 0.0) && finite_f64(blo) && finite_f64(bhi);
+    const int ef = __builtin_amdgcn_frexp_exp(bmin);  // bmin in [2^(ef-1), 2^ef)
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < NPK; ++k) {
+      const double tl = __builtin_fma(xlo, p.iw[k], p.cv[k]);
+      const double th = __builtin_fma(xhi, p.iw[k], p.cv[k]);
+      const bool same_side = (tl > 0.0 && th > 0.0) || (tl < 0.0 && th < 0.0);
+      const double al = fabs(tl), ah = fabs(th);
+      const double tmin = al < ah ? al : ah;
+      const double kd = __builtin_fma(-tmin, tmin, p.K.magic);
+      const int kmin = (int)__double_as_longlong(kd);  // |t| < 46000 on the fast path
+      const bool noop = same_side && (kmin <= ef + p.thr[k]);
+      m |= noop ? 0u : (1u << k);
+    }
+    // per LANE: sweep() gives each lane the range of a different tile (64 tiles per pass) and
+    // later broadcasts the tile's word with readlane, so the tests in eval() are scalar branches
+    return usable ? m : all;
+  }
   template <class PF>
   static __device__ __forceinline__ Prep prepare(PF pf, const FnDesc& fn) {
     Prep p;
     bool fast = true;
+    bool skip = fn.tile_skip != 0;
 #pragma unroll
     for (int j = 0; j < NBG; ++j) p.bg[j] = uniform_f64(pf(j));
     if (NBG > 1) {  // the first Horner step reads two coefficients: keep the leading one in a VGPR
@@ -359,16 +423,19 @@ struct PeaksModel {
       const double ta = fabs(__builtin_fma(fn.xmin, p.iw[k], p.mu[k]));
       const double tb = fabs(__builtin_fma(fn.xmax, p.iw[k], p.mu[k]));
       fast = fast && (ta < 46000.0) && (tb < 46000.0);
+      // |A_k| < 2^ea; a negative, infinite or NaN amplitude switches skipping off
+      skip = skip && (p.A[k] >= 0.0) && finite_f64(p.A[k]);
+      p.thr[k] = __builtin_amdgcn_readfirstlane(-__builtin_amdgcn_frexp_exp(p.A[k]) - 56);
     }
     p.fast = fast;
-    double c11 = kExp2C11;
-    asm volatile("" : "+v"(c11));
-    p.c11 = c11;
+    p.skip = skip && fast && kHasSkip;
+    p.K.pin();
     return p;
   }
   static __device__ __forceinline__ bool fast_ok(const Prep& p) { return p.fast; }
+  // mask (wave-uniform, from tile_mask): bit k clear = peak k is a no-op for this tile
   template <bool FAST>
-  static __device__ __forceinline__ double eval(const Prep& p, double x) {
+  static __device__ __forceinline__ double eval(const Prep& p, double x, unsigned mask = ~0u) {
     double f = 0.0;
     if (NBG > 0) {
       f = p.bg[NBG - 1];
@@ -377,11 +444,12 @@ struct PeaksModel {
     }
 #pragma unroll
     for (int k = 0; k < NPK; ++k) {
+      if (FAST && kHasSkip && !((mask >> k) & 1u)) continue;
       const double t = __builtin_fma(x, p.iw[k], p.cv[k]);
       if (LORENTZ)
         f = __builtin_fma(p.A[k], frcp(__builtin_fma(t, t, 1.0)), f);
       else
-        f = __builtin_fma(p.A[k], FAST ? mexp2_negsq(t, p.c11) : mexp2_negsq_safe(t), f);
+        f = __builtin_fma(p.A[k], FAST ? mexp2_negsq(t, p.K) : mexp2_negsq_safe(t), f);
     }
     return f;
   }
@@ -438,12 +506,23 @@ template <class M>
 struct model_has_fast<M, decltype((void)M::kHasFast, void())> {
   static constexpr bool value = M::kHasFast;
 };
+template <class M, class = void>
+struct model_has_skip { static constexpr bool value = false; };
+template <class M>
+struct model_has_skip<M, decltype((void)M::kHasSkip, void())> {
+  static constexpr bool value = M::kHasSkip;
+};
 template <class M, bool FAST>
-__device__ __forceinline__ double model_eval(const typename M::Prep& p, double x) {
-  if constexpr (model_has_fast<M>::value)
-    return M::template eval<FAST>(p, x);
-  else
+__device__ __forceinline__ double model_eval(const typename M::Prep& p, double x,
+                                             unsigned mask = ~0u) {
+  if constexpr (model_has_fast<M>::value) {
+    if constexpr (model_has_skip<M>::value)
+      return M::template eval<FAST>(p, x, mask);
+    else
+      return M::template eval<FAST>(p, x);
+  } else {
     return M::eval(p, x);
+  }
 }
 
 template <int NP>

@@ -70,7 +70,7 @@ struct DevBuf {
 };
 
 struct Dataset {
-  DevBuf<double> x, y, w, c;
+  DevBuf<double> x, y, w, c, txlo, txhi;
   bool set = false;
 };
 
@@ -146,9 +146,14 @@ int finalize_problem(mhx_engine* e) {
   // expression models / prior bodies: assign slots, compile once per distinct problem text
   std::vector<UserExpr> models, priors;
   bool builtin = false;
+  // MHX_NO_TILE_SKIP=1: evaluate every Gaussian peak at every point (the skipping is exact, so
+  // this only exists to show that the results do not change)
+  const char* nts = getenv("MHX_NO_TILE_SKIP");
+  const int tile_skip = (nts && atoi(nts) != 0) ? 0 : 1;
   for (int k = 0; k < e->P.K; ++k) {
     FnDesc& f = e->P.fn[k];
     f.user_slot = f.prior_slot = -1;
+    f.tile_skip = tile_skip;
     if (f.lik == MHX_LIK_EXPR) {
       if (e->lik_expr[k].empty())
         return fail(MHX_ESTATE, "dataset %d uses MHX_LIK_EXPR but mhx_set_likelihood_expr was "
@@ -558,11 +563,31 @@ int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y, cons
   HIP_TRY(hipMemcpy(D.y.p, hy.data(), np * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(D.w.p, hw.data(), np * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(D.c.p, hc.data(), np * sizeof(double), hipMemcpyHostToDevice));
+  // x range of every tile, pads included (tile-level peak skipping, PeaksModel::tile_mask)
+  const size_t ntp = std::max<size_t>(nt, 1);
+  std::vector<double> tlo(ntp), thi(ntp);
+  for (size_t t = 0; t < ntp; ++t) {
+    double lo = INFINITY, hi = -INFINITY;
+    bool ok = true;
+    for (size_t i = t * kTilePoints; i < (t + 1) * kTilePoints; ++i) {
+      ok = ok && std::isfinite(hx[i]);
+      lo = std::min(lo, hx[i]);
+      hi = std::max(hi, hx[i]);
+    }
+    tlo[t] = ok ? lo : -INFINITY;
+    thi[t] = ok ? hi : INFINITY;
+  }
+  if (D.txlo.alloc(ntp, false) != hipSuccess || D.txhi.alloc(ntp, false) != hipSuccess)
+    return fail(MHX_ENOMEM, "hipMalloc of dataset %d's tile ranges failed", k);
+  HIP_TRY(hipMemcpy(D.txlo.p, tlo.data(), ntp * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(D.txhi.p, thi.data(), ntp * sizeof(double), hipMemcpyHostToDevice));
   FnDesc& f = e->P.fn[k];
   f.x = D.x.p;
   f.y = D.y.p;
   f.w = D.w.p;
   f.c = D.c.p;
+  f.txlo = D.txlo.p;
+  f.txhi = D.txhi.p;
   f.n = (int64_t)n;
   f.n_tiles = (int64_t)nt;
   f.lik = likelihood;

@@ -54,6 +54,11 @@ __device__ __forceinline__ void tile_dma(const FnDesc& f, int64_t t, GroupLds& l
                                      (lds_ptr_t)&lds.tiles[buf][3][wbase], 16, 0, 0);
 }
 
+template <unsigned M>
+struct CMask {
+  constexpr operator unsigned() const { return M; }
+};
+
 // Sum over the points of function f.  Collective over the workgroup (barriers inside);
 // waves with active == false only help to move tiles.
 template <class Model, int LIK, bool FAST = false>
@@ -65,6 +70,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
   const int w = wave_in_group();
   const int64_t nt = f.n_tiles;
   double acc0 = 0.0, acc1 = 0.0;
+  unsigned tile_masks = ~0u;  // lane i: which peaks tile (t & ~63) + i needs (PeaksModel::tile_mask)
   if (nt == 0) return 0.0;
   tile_dma<NARR>(f, 0, lds, 0, w);
   // An LDS-DMA is ordered for the readers only by the ISSUING wave's vmcnt wait followed by a
@@ -81,60 +87,90 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
       const double* tw = lds.tiles[buf][2];
       const double* tc = lds.tiles[buf][3];
       const int64_t gbase = t * kTilePoints;
-      // Software-pipelined: the LDS reads of the next two points are issued before the dependent
-      // fp64 chain of the current two, so no wave waits on lgkmcnt.
-      double xa = tx[l], xb = tx[l + kWave], ya = ty[l], yb = ty[l + kWave];
-      double wa = 0, wb = 0, ca = 0, cb = 0;
-      if constexpr (NARR > 2) { wa = tw[l]; wb = tw[l + kWave]; }
-      if constexpr (NARR > 3) { ca = tc[l]; cb = tc[l + kWave]; }
-      // points of this tile that are data (the rest are neutral pads): short datasets such as
-      // test.lisp's 334 points leave most of their only tile unused
-      const int nv = (int)((f.n - gbase) < (int64_t)kTilePoints ? (f.n - gbase) : (int64_t)kTilePoints);
+      // One tile.  `mk` is the set of Gaussian peaks to evaluate: a run-time value, or a CMask<M>
+      // whose value is a compile-time constant once the lambda is inlined - the per-peak tests
+      // in PeaksModel::eval then fold away and each variant is straight-line code.
+      auto tile_body = [&](auto mk) {
+        const unsigned mask = mk;
+        // Software-pipelined: the LDS reads of the next two points are issued before the dependent
+        // fp64 chain of the current two, so no wave waits on lgkmcnt.
+        double xa = tx[l], xb = tx[l + kWave], ya = ty[l], yb = ty[l + kWave];
+        double wa = 0, wb = 0, ca = 0, cb = 0;
+        if constexpr (NARR > 2) { wa = tw[l]; wb = tw[l + kWave]; }
+        if constexpr (NARR > 3) { ca = tc[l]; cb = tc[l + kWave]; }
+        // points of this tile that are data (the rest are neutral pads): short datasets such as
+        // test.lisp's 334 points leave most of their only tile unused
+        const int nv = (int)((f.n - gbase) < (int64_t)kTilePoints ? (f.n - gbase) : (int64_t)kTilePoints);
 #pragma unroll
-      for (int k = 0; k < kTilePoints / kWave; k += 2) {
-        if (k * kWave >= nv) break;  // uniform: one scalar compare per two points
-        double xn = 0, xm = 0, yn = 0, ym = 0, wn = 0, wm = 0, cn = 0, cm = 0;
-        if (k + 2 < kTilePoints / kWave) {
-          const int j = (k + 2) * kWave + l;
-          xn = tx[j]; xm = tx[j + kWave];
-          yn = ty[j]; ym = ty[j + kWave];
-          if constexpr (NARR > 2) { wn = tw[j]; wm = tw[j + kWave]; }
-          if constexpr (NARR > 3) { cn = tc[j]; cm = tc[j + kWave]; }
+        for (int k = 0; k < kTilePoints / kWave; k += 2) {
+          if (k * kWave >= nv) break;  // uniform: one scalar compare per two points
+          double xn = 0, xm = 0, yn = 0, ym = 0, wn = 0, wm = 0, cn = 0, cm = 0;
+          if (k + 2 < kTilePoints / kWave) {
+            const int j = (k + 2) * kWave + l;
+            xn = tx[j]; xm = tx[j + kWave];
+            yn = ty[j]; ym = ty[j + kWave];
+            if constexpr (NARR > 2) { wn = tw[j]; wm = tw[j + kWave]; }
+            if constexpr (NARR > 3) { cn = tc[j]; cm = tc[j + kWave]; }
+          }
+          __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the arithmetic below
+          const double m0 = model_eval<Model, FAST>(prep, xa, mask);
+          const double m1 = model_eval<Model, FAST>(prep, xb, mask);
+          if constexpr (LIK == MHX_LIK_NORMAL) {
+            // the y array holds y/sigma (host, once): r = y/sigma - m/sigma in one fma
+            const double r0 = __builtin_fma(-m0, wa, ya), r1 = __builtin_fma(-m1, wb, yb);
+            acc0 = __builtin_fma(r0, r0, acc0);
+            acc1 = __builtin_fma(r1, r1, acc1);
+          } else if constexpr (LIK == MHX_LIK_NORMAL_CUTOFF) {
+            const double r0 = __builtin_fma(-m0, wa, ya), r1 = __builtin_fma(-m1, wb, yb);
+            const double t0 = __builtin_fma(-0.5 * r0, r0, ca);
+            const double t1 = __builtin_fma(-0.5 * r1, r1, cb);
+            acc0 = acc0 + (t0 > -5000.0 ? t0 : -5000.0);  // (max -5000d0 term) M:426
+            acc1 = acc1 + (t1 > -5000.0 ? t1 : -5000.0);
+            // pads carry c = 0, w = 0 -> max(-5000, 0) = 0
+          } else if constexpr (LIK == MHX_LIK_EXPR) {
+            // (funcall log-liklihood-function y (apply fn x params) stddev) M:415: the tiles hold
+            // y and sigma as given; pads masked
+            const double t0 = Model::lik_term(ya, m0, wa);
+            const double t1 = Model::lik_term(yb, m1, wb);
+            const int i0 = k * kWave + l;
+            acc0 = acc0 + ((gbase + i0) < f.n ? t0 : 0.0);
+            acc1 = acc1 + ((gbase + i0 + kWave) < f.n ? t1 : 0.0);
+          } else {
+            // (- (* k (log lambda)) lambda ...) M:383; pads masked (no neutral pad exists)
+            const double t0 = __builtin_fma(ya, mlog(m0), -m0);
+            const double t1 = __builtin_fma(yb, mlog(m1), -m1);
+            const int i0 = k * kWave + l;
+            acc0 = acc0 + ((gbase + i0) < f.n ? t0 : 0.0);
+            acc1 = acc1 + ((gbase + i0 + kWave) < f.n ? t1 : 0.0);
+          }
+          xa = xn; xb = xm; ya = yn; yb = ym;
+          if constexpr (NARR > 2) { wa = wn; wb = wm; }
+          if constexpr (NARR > 3) { ca = cn; cb = cm; }
         }
-        __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the arithmetic below
-        const double m0 = model_eval<Model, FAST>(prep, xa);
-        const double m1 = model_eval<Model, FAST>(prep, xb);
-        if constexpr (LIK == MHX_LIK_NORMAL) {
-          // the y array holds y/sigma (host, once): r = y/sigma - m/sigma in one fma
-          const double r0 = __builtin_fma(-m0, wa, ya), r1 = __builtin_fma(-m1, wb, yb);
-          acc0 = __builtin_fma(r0, r0, acc0);
-          acc1 = __builtin_fma(r1, r1, acc1);
-        } else if constexpr (LIK == MHX_LIK_NORMAL_CUTOFF) {
-          const double r0 = __builtin_fma(-m0, wa, ya), r1 = __builtin_fma(-m1, wb, yb);
-          const double t0 = __builtin_fma(-0.5 * r0, r0, ca);
-          const double t1 = __builtin_fma(-0.5 * r1, r1, cb);
-          acc0 = acc0 + (t0 > -5000.0 ? t0 : -5000.0);  // (max -5000d0 term) M:426
-          acc1 = acc1 + (t1 > -5000.0 ? t1 : -5000.0);
-          // pads carry c = 0, w = 0 -> max(-5000, 0) = 0
-        } else if constexpr (LIK == MHX_LIK_EXPR) {
-          // (funcall log-liklihood-function y (apply fn x params) stddev) M:415: the tiles hold
-          // y and sigma as given; pads masked
-          const double t0 = Model::lik_term(ya, m0, wa);
-          const double t1 = Model::lik_term(yb, m1, wb);
-          const int i0 = k * kWave + l;
-          acc0 = acc0 + ((gbase + i0) < f.n ? t0 : 0.0);
-          acc1 = acc1 + ((gbase + i0 + kWave) < f.n ? t1 : 0.0);
+      };
+      // Gaussian peaks that cannot change any sum of this tile by even one bit are left out
+      // (PeaksModel::tile_mask; exact, so the results do not depend on it)
+      if constexpr (FAST && model_has_skip<Model>::value) {
+        // the masks of 64 consecutive tiles are worked out at once, lane i taking tile t + i
+        if ((t & 63) == 0) {
+          const int64_t ti = t + l < nt ? t + l : nt - 1;
+          tile_masks = Model::tile_mask(prep, f.txlo[ti], f.txhi[ti]);
+        }
+        const unsigned tm = (unsigned)__builtin_amdgcn_readlane((int)tile_masks, (int)(t & 63));
+        if constexpr (Model::kPeaks == 1) {
+          if (tm & 1u) tile_body(CMask<1u>{}); else tile_body(CMask<0u>{});
+        } else if constexpr (Model::kPeaks == 2) {
+          switch (tm & 3u) {
+            case 0u: tile_body(CMask<0u>{}); break;
+            case 1u: tile_body(CMask<1u>{}); break;
+            case 2u: tile_body(CMask<2u>{}); break;
+            default: tile_body(CMask<3u>{}); break;
+          }
         } else {
-          // (- (* k (log lambda)) lambda ...) M:383; pads masked (no neutral pad exists)
-          const double t0 = __builtin_fma(ya, mlog(m0), -m0);
-          const double t1 = __builtin_fma(yb, mlog(m1), -m1);
-          const int i0 = k * kWave + l;
-          acc0 = acc0 + ((gbase + i0) < f.n ? t0 : 0.0);
-          acc1 = acc1 + ((gbase + i0 + kWave) < f.n ? t1 : 0.0);
+          tile_body(tm);  // more peaks: wave-uniform branches around each peak
         }
-        xa = xn; xb = xm; ya = yn; yb = ym;
-        if constexpr (NARR > 2) { wa = wn; wb = wm; }
-        if constexpr (NARR > 3) { ca = cn; cb = cm; }
+      } else {
+        tile_body(CMask<~0u>{});
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of tile t+1 has landed

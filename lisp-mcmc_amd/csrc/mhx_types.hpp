@@ -43,6 +43,10 @@ struct FnDesc {
   int64_t n_tiles;  // ceil(n / kTilePoints)
   double lik_const; // normal: sum_i(-1/2 log 2pi - log sigma_i); poisson: -sum_i logfact(k_i)
   double xmin, xmax; // range of x over the n points (fast-path preconditions of the models)
+  const double* txlo;  // [n_tiles] smallest / largest x of each tile (-inf / +inf when a tile
+  const double* txhi;  // holds a non-finite x): what tile-level peak skipping tests against
+  int32_t tile_skip;   // 0: evaluate every peak for every point (MHX_NO_TILE_SKIP=1)
+  int32_t pad_;
   int32_t user_slot;  // >= 0: index of the run-time compiled expression model (MHX_MODEL_EXPR)
   int32_t prior_slot; // >= 0: index of the run-time compiled prior body, else -1
 };
