@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmhx.so")
+LIB_PATH = os.environ.get("MHX_LIBRARY") or os.path.join(_HERE, "libmhx.so")  # MHX_LIBRARY: a tuning build
 
 f64p = C.POINTER(C.c_double)
 i32p = C.POINTER(C.c_int32)

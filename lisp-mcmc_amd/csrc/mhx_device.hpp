@@ -15,7 +15,30 @@
 
 #include "mhx_types.hpp"
 
+// build knobs of one family of kernels (see mhx_types.hpp); the Makefile compiles
+// mhx_kernels.hip once per family, hiprtc gets the same defines for expression kernels
+#ifndef MHX_WPG
+#define MHX_WPG 8
+#endif
+#ifndef MHX_FAMILY
+#define MHX_FAMILY w8
+#endif
+#ifndef MHX_PPI
+// data points per lane and inner-loop iteration: 8 iterations per tile in either family (the
+// fully unrolled loop of 16 two-point iterations is more than the unroller accepts, and a rolled
+// loop loses the software pipeline); 2 keeps the pad evaluations of short datasets low (w8)
+#define MHX_PPI (MHX_WPG >= 16 ? 4 : 2)
+#endif
+#ifndef MHX_PPI_MASKED
+#define MHX_PPI_MASKED 4  // the same where Gaussian peaks are skipped through run-time branches
+#endif
+
 namespace mhx {
+inline namespace MHX_FAMILY {
+
+constexpr int kWavesPerGroup = MHX_WPG;     // one wave = one chain; a workgroup shares LDS tiles
+constexpr int kThreads = kWave * kWavesPerGroup;
+constexpr int kTilePoints = tile_points_of(kWavesPerGroup);  // data points per LDS tile and array
 
 // ------------------------------------------------------------------------------------------
 // wave helpers
@@ -453,6 +476,35 @@ struct PeaksModel {
     }
     return f;
   }
+  // The same for P points at once, peak by peak: with a run-time mask every peak is a basic
+  // block of its own, and evaluating the P points inside it gives the block P independent fp64
+  // chains (a dependent v_fma_f64 can issue only every other slot: tools/microbench/fma_chain).
+  // Each point's operations and their order are those of eval(): identical bits.
+  template <bool FAST, int P>
+  static __device__ __forceinline__ void eval_n(const Prep& p, const double (&x)[P], unsigned mask,
+                                                double (&f)[P]) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      f[i] = 0.0;
+      if (NBG > 0) {
+        f[i] = p.bg[NBG - 1];
+#pragma unroll
+        for (int j = NBG - 2; j >= 0; --j) f[i] = __builtin_fma(f[i], x[i], p.bg[j]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NPK; ++k) {
+      if (FAST && kHasSkip && !((mask >> k) & 1u)) continue;
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        const double t = __builtin_fma(x[i], p.iw[k], p.cv[k]);
+        if (LORENTZ)
+          f[i] = __builtin_fma(p.A[k], frcp(__builtin_fma(t, t, 1.0)), f[i]);
+        else
+          f[i] = __builtin_fma(p.A[k], FAST ? mexp2_negsq(t, p.K) : mexp2_negsq_safe(t), f[i]);
+      }
+    }
+  }
 };
 
 // any (nbg, npk): parameters stay in the wave's LDS slot and are re-read per point
@@ -522,6 +574,23 @@ __device__ __forceinline__ double model_eval(const typename M::Prep& p, double x
       return M::template eval<FAST>(p, x);
   } else {
     return M::eval(p, x);
+  }
+}
+template <class M, class = void>
+struct model_peaks { static constexpr int value = 0; };
+template <class M>
+struct model_peaks<M, decltype((void)M::kPeaks, void())> {
+  static constexpr int value = M::kPeaks;
+};
+// P points of one lane at once (models without an eval_n of their own: point after point)
+template <class M, bool FAST, int P>
+__device__ __forceinline__ void model_eval_n(const typename M::Prep& p, const double (&x)[P],
+                                             unsigned mask, double (&f)[P]) {
+  if constexpr (model_has_skip<M>::value) {
+    M::template eval_n<FAST, P>(p, x, mask, f);
+  } else {
+#pragma unroll
+    for (int i = 0; i < P; ++i) f[i] = model_eval<M, FAST>(p, x[i], mask);
   }
 }
 
@@ -642,4 +711,5 @@ struct PVoigt2Model {
   }
 };
 
+}  // inline namespace MHX_FAMILY
 }  // namespace mhx

@@ -71,6 +71,7 @@ struct DevBuf {
 
 struct Dataset {
   DevBuf<double> x, y, w, c, txlo, txhi;
+  std::vector<double> hx;  // host copy of the padded x: tile ranges are formed per kernel family
   bool set = false;
 };
 
@@ -102,6 +103,7 @@ struct mhx_engine {
   std::unique_ptr<UserProgram> user_prog;
   std::string user_key;
   int spec = SPEC_GENERIC;
+  const Family* fam = &family_w8();  // kernel family (workgroup shape) of the current problem
 
   ChainState S{};
   DevBuf<double> theta, prob, best_theta, best_prob, hist_prob, hist_theta, L, temperature,
@@ -137,11 +139,56 @@ int use_device(mhx_engine* e) {
   return MHX_OK;
 }
 
+// Which workgroup shape serves this problem (mhx_types.hpp).  16 chains per workgroup and
+// 2048-point tiles pay off when the datasets are long (>= 4 such tiles) and there are enough
+// chains to give every CU its one workgroup; otherwise 8 chains per workgroup (more, smaller
+// workgroups; less barrier and pad overhead on short datasets).  MHX_FAMILY_WPG=8|16 pins it.
+const Family& choose_family(const mhx_engine* e) {
+  if (const char* s = getenv("MHX_FAMILY_WPG")) {
+    if (atoi(s) == 16) return family_w16();
+    if (atoi(s) == 8) return family_w8();
+  }
+  int64_t longest = 0;
+  for (int k = 0; k < e->P.K; ++k) longest = std::max<int64_t>(longest, e->P.fn[k].n);
+  const bool big = longest >= 4 * (int64_t)family_w16().tile_points &&
+                   e->cfg.n_chains >= 16 * 256;
+  return big ? family_w16() : family_w8();
+}
+
 int finalize_problem(mhx_engine* e) {
   if (!e->problem_dirty) return MHX_OK;
   for (int k = 0; k < e->P.K; ++k) {
     if (!e->fn_set[k]) return fail(MHX_ESTATE, "function %d was never set (mhx_set_function)", k);
     if (!e->data[k].set) return fail(MHX_ESTATE, "dataset %d was never set (mhx_set_dataset)", k);
+  }
+  // the kernel family fixes the tile size: tiles per dataset and the x range of every tile, pads
+  // included (tile-level peak skipping, PeaksModel::tile_mask)
+  e->fam = &choose_family(e);
+  const size_t tp = (size_t)e->fam->tile_points;
+  for (int k = 0; k < e->P.K; ++k) {
+    FnDesc& f = e->P.fn[k];
+    Dataset& D = e->data[k];
+    const size_t nt = ((size_t)f.n + tp - 1) / tp;
+    const size_t ntp = std::max<size_t>(nt, 1);
+    std::vector<double> tlo(ntp), thi(ntp);
+    for (size_t t = 0; t < ntp; ++t) {
+      double lo = INFINITY, hi = -INFINITY;
+      bool ok = true;
+      for (size_t i = t * tp; i < (t + 1) * tp; ++i) {
+        ok = ok && std::isfinite(D.hx[i]);
+        lo = std::min(lo, D.hx[i]);
+        hi = std::max(hi, D.hx[i]);
+      }
+      tlo[t] = ok ? lo : -INFINITY;
+      thi[t] = ok ? hi : INFINITY;
+    }
+    if (D.txlo.alloc(ntp, false) != hipSuccess || D.txhi.alloc(ntp, false) != hipSuccess)
+      return fail(MHX_ENOMEM, "hipMalloc of dataset %d's tile ranges failed", k);
+    HIP_TRY(hipMemcpy(D.txlo.p, tlo.data(), ntp * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(D.txhi.p, thi.data(), ntp * sizeof(double), hipMemcpyHostToDevice));
+    f.txlo = D.txlo.p;
+    f.txhi = D.txhi.p;
+    f.n_tiles = (int64_t)nt;
   }
   // expression models / prior bodies: assign slots, compile once per distinct problem text
   std::vector<UserExpr> models, priors;
@@ -188,10 +235,11 @@ int finalize_problem(mhx_engine* e) {
       key += "M:" + u.expr + "|" + sig(u) + "|L" + std::to_string(u.lik) + ":" + u.lik_expr + "|";
     for (auto& u : priors) key += "P:" + u.expr + "|" + sig(u) + "|";
     key += builtin ? "B1" : "B0";
+    key += "|W" + std::to_string(e->fam->waves_per_group);
     if (!e->user_prog || key != e->user_key) {
       std::unique_ptr<UserProgram> prog(new UserProgram());
       std::string err;
-      if (rtc_build(models, priors, builtin, prog.get(), &err) != 0)
+      if (rtc_build(models, priors, builtin, *e->fam, prog.get(), &err) != 0)
         return fail(MHX_EUNSUPPORTED, "%s", err.c_str());
       e->user_prog = std::move(prog);
       e->user_key = key;
@@ -210,22 +258,22 @@ int finalize_problem(mhx_engine* e) {
 hipError_t do_logpost(mhx_engine* e, const double* th, int64_t n, double* out, double* parts) {
   return e->spec == SPEC_USER
              ? rtc_launch_logpost(*e->user_prog, e->stream, e->dP.p, th, n, out, parts)
-             : launch_logpost(e->spec, e->stream, e->dP.p, th, n, out, parts);
+             : e->fam->logpost(e->spec, e->stream, e->dP.p, th, n, out, parts);
 }
 hipError_t do_init(mhx_engine* e) {
   return e->spec == SPEC_USER ? rtc_launch_init(*e->user_prog, e->stream, e->dP.p, e->S)
-                              : launch_init(e->spec, e->stream, e->dP.p, e->S);
+                              : e->fam->init(e->spec, e->stream, e->dP.p, e->S);
 }
 hipError_t do_step_injected(mhx_engine* e, const double* L, int pcl, const double* z,
                             const double* u, const double* T, unsigned char* acc) {
   return e->spec == SPEC_USER
              ? rtc_launch_step_injected(*e->user_prog, e->stream, e->dP.p, e->S, L, pcl, z, u, T, acc)
-             : launch_step_injected(e->spec, e->stream, e->dP.p, e->S, L, pcl, z, u, T, acc);
+             : e->fam->step_injected(e->spec, e->stream, e->dP.p, e->S, L, pcl, z, u, T, acc);
 }
 hipError_t do_adaptive(mhx_engine* e, int64_t iters, int plain) {
   return e->spec == SPEC_USER
              ? rtc_launch_adaptive(*e->user_prog, e->stream, e->dP.p, e->S, e->R, iters, plain)
-             : launch_adaptive(e->spec, e->stream, e->dP.p, e->S, e->R, iters, plain);
+             : e->fam->adaptive(e->spec, e->stream, e->dP.p, e->S, e->R, iters, plain);
 }
 
 int check_model(int model, const int32_t* shape, int n_shape, int n_index) {
@@ -368,8 +416,8 @@ int launch_steps(mhx_engine* e, int64_t iters, int plain) {
 // torch.distributed, or any MPI-like sum) -> covariance, Cholesky, 2.38^2/d on every rank.
 int pool_refresh(mhx_engine* e) {
   const size_t E = 1 + (size_t)e->P.d + (size_t)e->P.d * e->P.d;
-  HIP_TRY(launch_pool_stats(e->stream, e->S, e->R));
-  HIP_TRY(launch_pool_reduce(e->stream, e->S));
+  HIP_TRY(e->fam->pool_stats(e->stream, e->S, e->R));
+  HIP_TRY(e->fam->pool_reduce(e->stream, e->S));
   if (e->allreduce) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     int rc;
@@ -384,7 +432,7 @@ int pool_refresh(mhx_engine* e) {
     }
     if (rc != 0) return fail(MHX_ECOMM, "all-reduce hook returned %d", rc);
   }
-  HIP_TRY(launch_pool_factor(e->stream, e->S));
+  HIP_TRY(e->fam->pool_factor(e->stream, e->S));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->launches += 3;
   e->pool_refreshes++;
@@ -452,9 +500,9 @@ int mhx_create(const mhx_config* cfg, mhx_engine** out) {
       rc = fail(MHX_EDEVICE, "stream/event creation failed");
       break;
     }
-    if (configure_kernels() != hipSuccess) {
-      rc = fail(MHX_EDEVICE, "hipFuncSetAttribute(max dynamic LDS = %zu) failed",
-                group_lds_bytes());
+    if (family_w8().configure() != hipSuccess || family_w16().configure() != hipSuccess) {
+      rc = fail(MHX_EDEVICE, "hipFuncSetAttribute(max dynamic LDS = %zu / %zu) failed",
+                family_w8().lds_bytes, family_w16().lds_bytes);
       break;
     }
     if (e->dP.alloc(1) != hipSuccess) {
@@ -520,8 +568,8 @@ int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y, cons
     return fail(MHX_EINVAL, "unknown likelihood %d", likelihood);
   int rc = use_device(e);
   if (rc != MHX_OK) return rc;
-  const size_t nt = (n + kTilePoints - 1) / kTilePoints;
-  const size_t np = std::max<size_t>(nt, 1) * kTilePoints;
+  // padded to a whole number of tiles of either kernel family
+  const size_t np = std::max<size_t>((n + kPadPoints - 1) / kPadPoints, 1) * kPadPoints;
   std::vector<double> hx(np), hy(np), hw(np), hc(np);
   long double csum = 0.0L;
   const double half_log_2pi = -0.5 * std::log(2.0 * M_PI);  // (* -1/2 (log (* 2 pi))) M:377
@@ -563,33 +611,15 @@ int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y, cons
   HIP_TRY(hipMemcpy(D.y.p, hy.data(), np * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(D.w.p, hw.data(), np * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(D.c.p, hc.data(), np * sizeof(double), hipMemcpyHostToDevice));
-  // x range of every tile, pads included (tile-level peak skipping, PeaksModel::tile_mask)
-  const size_t ntp = std::max<size_t>(nt, 1);
-  std::vector<double> tlo(ntp), thi(ntp);
-  for (size_t t = 0; t < ntp; ++t) {
-    double lo = INFINITY, hi = -INFINITY;
-    bool ok = true;
-    for (size_t i = t * kTilePoints; i < (t + 1) * kTilePoints; ++i) {
-      ok = ok && std::isfinite(hx[i]);
-      lo = std::min(lo, hx[i]);
-      hi = std::max(hi, hx[i]);
-    }
-    tlo[t] = ok ? lo : -INFINITY;
-    thi[t] = ok ? hi : INFINITY;
-  }
-  if (D.txlo.alloc(ntp, false) != hipSuccess || D.txhi.alloc(ntp, false) != hipSuccess)
-    return fail(MHX_ENOMEM, "hipMalloc of dataset %d's tile ranges failed", k);
-  HIP_TRY(hipMemcpy(D.txlo.p, tlo.data(), ntp * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(D.txhi.p, thi.data(), ntp * sizeof(double), hipMemcpyHostToDevice));
   FnDesc& f = e->P.fn[k];
   f.x = D.x.p;
   f.y = D.y.p;
   f.w = D.w.p;
   f.c = D.c.p;
-  f.txlo = D.txlo.p;
-  f.txhi = D.txhi.p;
+  f.txlo = f.txhi = nullptr;  // per-tile x ranges and n_tiles: finalize_problem, per family
   f.n = (int64_t)n;
-  f.n_tiles = (int64_t)nt;
+  f.n_tiles = 0;
+  D.hx.swap(hx);
   f.lik = likelihood;
   f.lik_const = (double)csum;
   f.xmin = f.xmax = n ? x[0] : 0.0;
@@ -825,7 +855,7 @@ int mhx_adaptive_begin(mhx_engine* e, const mhx_run_opts* o) {
       HIP_TRY(hipMemcpy(e->L.p, full.data(), full.size() * sizeof(double), hipMemcpyHostToDevice));
     }
   }
-  HIP_TRY(launch_initial_l(e->stream, e->S, R, o->l_matrix ? 1 : 0, o->temperature));
+  HIP_TRY(e->fam->initial_l(e->stream, e->S, R, o->l_matrix ? 1 : 0, o->temperature));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->launches++;
   e->run_ready = true;
@@ -999,7 +1029,7 @@ int mhx_get_acceptance(mhx_engine* e, int take, double* out) {
   DevBuf<double> d;
   const size_t C = (size_t)e->cfg.n_chains;
   if (d.alloc(C, false) != hipSuccess) return fail(MHX_ENOMEM, "hipMalloc failed");
-  HIP_TRY(launch_acceptance(e->stream, e->S, take, d.p));
+  HIP_TRY(e->fam->acceptance(e->stream, e->S, take, d.p));
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipMemcpy(out, d.p, C * sizeof(double), hipMemcpyDeviceToHost));
   return MHX_OK;
@@ -1052,7 +1082,7 @@ int mhx_get_proposal_factor(mhx_engine* e, int64_t chain, int take, double* L_ou
   if (fwd.alloc((size_t)take) != hipSuccess || info.alloc(2) != hipSuccess ||
       cov.alloc(dd) != hipSuccess || out.alloc(dd) != hipSuccess)
     return fail(MHX_ENOMEM, "hipMalloc failed");
-  HIP_TRY(launch_l_matrix(e->stream, e->S, chain, take, fwd.p, cov.p, out.p, info.p));
+  HIP_TRY(e->fam->l_matrix(e->stream, e->S, chain, take, fwd.p, cov.p, out.p, info.p));
   HIP_TRY(hipStreamSynchronize(e->stream));
   int32_t hinfo[2];
   HIP_TRY(hipMemcpy(hinfo, info.p, sizeof hinfo, hipMemcpyDeviceToHost));
@@ -1116,7 +1146,7 @@ int mhx_walker_modify(mhx_engine* e, int action, int64_t n) {
                     action == MHX_MODIFY_BURN_WALKS ? ":burn-number" : ":keep-number",
                     (long long)n, (long long)v);
   }
-  HIP_TRY(launch_modify(e->stream, e->S, action, n));
+  HIP_TRY(e->fam->modify(e->stream, e->S, action, n));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->launches++;
   return MHX_OK;

@@ -19,6 +19,7 @@
 #include "mhx_device.hpp"
 
 namespace mhx {
+inline namespace MHX_FAMILY {
 
 struct GroupLds {
   double tiles[2][kMaxArrays][kTilePoints];        // 64 KiB
@@ -92,60 +93,80 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
       // in PeaksModel::eval then fold away and each variant is straight-line code.
       auto tile_body = [&](auto mk) {
         const unsigned mask = mk;
-        // Software-pipelined: the LDS reads of the next two points are issued before the dependent
-        // fp64 chain of the current two, so no wave waits on lgkmcnt.
-        double xa = tx[l], xb = tx[l + kWave], ya = ty[l], yb = ty[l + kWave];
-        double wa = 0, wb = 0, ca = 0, cb = 0;
-        if constexpr (NARR > 2) { wa = tw[l]; wb = tw[l + kWave]; }
-        if constexpr (NARR > 3) { ca = tc[l]; cb = tc[l + kWave]; }
+        // P points per lane and iteration: point i of iteration it is element (it*P + i)*64 + l
+        // of the tile.  Software-pipelined: the LDS reads of the next P points are issued before
+        // the dependent fp64 chains of the current ones, so no wave waits on lgkmcnt.  P = 2
+        // everywhere (a short dataset then evaluates the fewest pads: test.lisp's 334 points
+        // cost 6 evaluations per lane with P = 2, 8 with P = 4) except where every peak is a basic
+        // block of its own (run-time mask, more than 2 peaks): there 4 points give the block four
+        // independent fp64 chains (+5 % on BASELINE config 3).
+        constexpr int P = (FAST && model_has_skip<Model>::value && model_peaks<Model>::value > 2)
+                              ? MHX_PPI_MASKED : MHX_PPI;
+        constexpr int NIT = kTilePoints / kWave / P;
+        static_assert(kTilePoints % (kWave * P) == 0, "whole iterations per tile");
+        double x[P], y[P], wv[P], cv[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+          x[i] = tx[i * kWave + l];
+          y[i] = ty[i * kWave + l];
+          wv[i] = 0.0;
+          cv[i] = 0.0;
+          if constexpr (NARR > 2) wv[i] = tw[i * kWave + l];
+          if constexpr (NARR > 3) cv[i] = tc[i * kWave + l];
+        }
         // points of this tile that are data (the rest are neutral pads): short datasets such as
         // test.lisp's 334 points leave most of their only tile unused
         const int nv = (int)((f.n - gbase) < (int64_t)kTilePoints ? (f.n - gbase) : (int64_t)kTilePoints);
 #pragma unroll
-        for (int k = 0; k < kTilePoints / kWave; k += 2) {
-          if (k * kWave >= nv) break;  // uniform: one scalar compare per two points
-          double xn = 0, xm = 0, yn = 0, ym = 0, wn = 0, wm = 0, cn = 0, cm = 0;
-          if (k + 2 < kTilePoints / kWave) {
-            const int j = (k + 2) * kWave + l;
-            xn = tx[j]; xm = tx[j + kWave];
-            yn = ty[j]; ym = ty[j + kWave];
-            if constexpr (NARR > 2) { wn = tw[j]; wm = tw[j + kWave]; }
-            if constexpr (NARR > 3) { cn = tc[j]; cm = tc[j + kWave]; }
+        for (int it = 0; it < NIT; ++it) {
+          if (it * P * kWave >= nv) break;  // uniform: one scalar compare per P points
+          double xn[P], yn[P], wn[P], cn[P];
+#pragma unroll
+          for (int i = 0; i < P; ++i) {
+            xn[i] = yn[i] = wn[i] = cn[i] = 0.0;
+            if (it + 1 < NIT) {
+              const int j = ((it + 1) * P + i) * kWave + l;
+              xn[i] = tx[j];
+              yn[i] = ty[j];
+              if constexpr (NARR > 2) wn[i] = tw[j];
+              if constexpr (NARR > 3) cn[i] = tc[j];
+            }
           }
           __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the arithmetic below
-          const double m0 = model_eval<Model, FAST>(prep, xa, mask);
-          const double m1 = model_eval<Model, FAST>(prep, xb, mask);
-          if constexpr (LIK == MHX_LIK_NORMAL) {
-            // the y array holds y/sigma (host, once): r = y/sigma - m/sigma in one fma
-            const double r0 = __builtin_fma(-m0, wa, ya), r1 = __builtin_fma(-m1, wb, yb);
-            acc0 = __builtin_fma(r0, r0, acc0);
-            acc1 = __builtin_fma(r1, r1, acc1);
-          } else if constexpr (LIK == MHX_LIK_NORMAL_CUTOFF) {
-            const double r0 = __builtin_fma(-m0, wa, ya), r1 = __builtin_fma(-m1, wb, yb);
-            const double t0 = __builtin_fma(-0.5 * r0, r0, ca);
-            const double t1 = __builtin_fma(-0.5 * r1, r1, cb);
-            acc0 = acc0 + (t0 > -5000.0 ? t0 : -5000.0);  // (max -5000d0 term) M:426
-            acc1 = acc1 + (t1 > -5000.0 ? t1 : -5000.0);
-            // pads carry c = 0, w = 0 -> max(-5000, 0) = 0
-          } else if constexpr (LIK == MHX_LIK_EXPR) {
-            // (funcall log-liklihood-function y (apply fn x params) stddev) M:415: the tiles hold
-            // y and sigma as given; pads masked
-            const double t0 = Model::lik_term(ya, m0, wa);
-            const double t1 = Model::lik_term(yb, m1, wb);
-            const int i0 = k * kWave + l;
-            acc0 = acc0 + ((gbase + i0) < f.n ? t0 : 0.0);
-            acc1 = acc1 + ((gbase + i0 + kWave) < f.n ? t1 : 0.0);
-          } else {
-            // (- (* k (log lambda)) lambda ...) M:383; pads masked (no neutral pad exists)
-            const double t0 = __builtin_fma(ya, mlog(m0), -m0);
-            const double t1 = __builtin_fma(yb, mlog(m1), -m1);
-            const int i0 = k * kWave + l;
-            acc0 = acc0 + ((gbase + i0) < f.n ? t0 : 0.0);
-            acc1 = acc1 + ((gbase + i0 + kWave) < f.n ? t1 : 0.0);
+          double m[P];
+          model_eval_n<Model, FAST, P>(prep, x, mask, m);
+          // even points feed acc0, odd points acc1, each in increasing point order: the summation
+          // order the oracle's mirror mode restates
+#pragma unroll
+          for (int i = 0; i < P; ++i) {
+            double& acc = (i & 1) ? acc1 : acc0;
+            if constexpr (LIK == MHX_LIK_NORMAL) {
+              // the y array holds y/sigma (host, once): r = y/sigma - m/sigma in one fma
+              const double r = __builtin_fma(-m[i], wv[i], y[i]);
+              acc = __builtin_fma(r, r, acc);
+            } else if constexpr (LIK == MHX_LIK_NORMAL_CUTOFF) {
+              const double r = __builtin_fma(-m[i], wv[i], y[i]);
+              const double tt = __builtin_fma(-0.5 * r, r, cv[i]);
+              acc = acc + (tt > -5000.0 ? tt : -5000.0);  // (max -5000d0 term) M:426
+              // pads carry c = 0, w = 0 -> max(-5000, 0) = 0
+            } else if constexpr (LIK == MHX_LIK_EXPR) {
+              // (funcall log-liklihood-function y (apply fn x params) stddev) M:415: the tiles
+              // hold y and sigma as given; pads masked
+              const double tt = Model::lik_term(y[i], m[i], wv[i]);
+              acc = acc + ((gbase + (it * P + i) * kWave + l) < f.n ? tt : 0.0);
+            } else {
+              // (- (* k (log lambda)) lambda ...) M:383; pads masked (no neutral pad exists)
+              const double tt = __builtin_fma(y[i], mlog(m[i]), -m[i]);
+              acc = acc + ((gbase + (it * P + i) * kWave + l) < f.n ? tt : 0.0);
+            }
           }
-          xa = xn; xb = xm; ya = yn; yb = ym;
-          if constexpr (NARR > 2) { wa = wn; wb = wm; }
-          if constexpr (NARR > 3) { ca = cn; cb = cm; }
+#pragma unroll
+          for (int i = 0; i < P; ++i) {
+            x[i] = xn[i];
+            y[i] = yn[i];
+            wv[i] = wn[i];
+            cv[i] = cn[i];
+          }
         }
       };
       // Gaussian peaks that cannot change any sum of this tile by even one bit are left out
@@ -1082,5 +1103,6 @@ __global__ __launch_bounds__(kThreads) void k_acceptance(ChainState S, int take,
   if (l == 0) out[c] = (double)num / (double)den;
 }
 
+}  // inline namespace MHX_FAMILY
 }  // namespace mhx
 

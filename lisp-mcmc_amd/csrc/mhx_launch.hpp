@@ -1,4 +1,5 @@
-// mhx_launch.hpp -- host-callable launchers of the gfx950 kernels (defined in mhx_kernels.hip).
+// mhx_launch.hpp -- host-callable launchers of the gfx950 kernels (defined in mhx_kernels.hip,
+// once per kernel family: see mhx_types.hpp).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -24,26 +25,33 @@ enum SpecId {
 int select_spec(const ProblemDesc& P);
 const char* spec_name(int spec);
 
-hipError_t configure_kernels();
-size_t group_lds_bytes();
+// One family of kernels: everything that depends on the workgroup shape goes through this table.
+struct Family {
+  int waves_per_group;  // chains per workgroup
+  int threads;          // 64 * waves_per_group
+  int tile_points;      // data points per LDS tile and array
+  size_t lds_bytes;     // dynamic LDS of the stepping kernels
+  hipError_t (*configure)();
+  hipError_t (*logpost)(int spec, hipStream_t st, const ProblemDesc* P, const double* theta,
+                        int64_t n, double* out, double* parts);
+  hipError_t (*init)(int spec, hipStream_t st, const ProblemDesc* P, const ChainState& S);
+  hipError_t (*step_injected)(int spec, hipStream_t st, const ProblemDesc* P, const ChainState& S,
+                              const double* L, int per_chain_l, const double* z, const double* u,
+                              const double* T, unsigned char* accepted);
+  hipError_t (*adaptive)(int spec, hipStream_t st, const ProblemDesc* P, const ChainState& S,
+                         const RunDesc& R, int64_t max_iters, int plain);
+  hipError_t (*initial_l)(hipStream_t st, const ChainState& S, const RunDesc& R, int have_l,
+                          double T0);
+  hipError_t (*l_matrix)(hipStream_t st, const ChainState& S, int64_t chain, int take, int* fwd,
+                         double* cov, double* out, int* info);
+  hipError_t (*acceptance)(hipStream_t st, const ChainState& S, int take, double* out);
+  hipError_t (*pool_stats)(hipStream_t st, const ChainState& S, const RunDesc& R);
+  hipError_t (*pool_reduce)(hipStream_t st, const ChainState& S);
+  hipError_t (*pool_factor)(hipStream_t st, const ChainState& S);
+  hipError_t (*modify)(hipStream_t st, const ChainState& S, int action, int64_t n);
+};
 
-hipError_t launch_logpost(int spec, hipStream_t st, const ProblemDesc* P, const double* theta,
-                          int64_t n, double* out, double* parts);
-hipError_t launch_init(int spec, hipStream_t st, const ProblemDesc* P, const ChainState& S);
-hipError_t launch_step_injected(int spec, hipStream_t st, const ProblemDesc* P,
-                                const ChainState& S, const double* L, int per_chain_l,
-                                const double* z, const double* u, const double* T,
-                                unsigned char* accepted);
-hipError_t launch_adaptive(int spec, hipStream_t st, const ProblemDesc* P, const ChainState& S,
-                           const RunDesc& R, int64_t max_iters, int plain);
-hipError_t launch_initial_l(hipStream_t st, const ChainState& S, const RunDesc& R, int have_l,
-                            double T0);
-hipError_t launch_l_matrix(hipStream_t st, const ChainState& S, int64_t chain, int take, int* fwd,
-                           double* cov, double* out, int* info);
-hipError_t launch_acceptance(hipStream_t st, const ChainState& S, int take, double* out);
-hipError_t launch_pool_stats(hipStream_t st, const ChainState& S, const RunDesc& R);
-hipError_t launch_pool_reduce(hipStream_t st, const ChainState& S);
-hipError_t launch_pool_factor(hipStream_t st, const ChainState& S);
-hipError_t launch_modify(hipStream_t st, const ChainState& S, int action, int64_t n);
+const Family& family_w8();
+const Family& family_w16();
 
 }  // namespace mhx

@@ -158,9 +158,10 @@ int rtc_prepare_expr(const std::string& expr, const std::vector<std::string>& na
 // ---- source generation --------------------------------------------------------------------------
 static std::string generate(const std::vector<UserExpr>& models,
                             const std::vector<UserExpr>& priors, bool builtin_fallback,
-                            int min_waves) {
+                            int min_waves, int threads) {
   std::ostringstream s;
-  s << "#include \"mhx_kernels.hpp\"\n"
+  s << "#define MHX_USER_THREADS " << threads << "\n"
+    << "#include \"mhx_kernels.hpp\"\n"
        "namespace mhx {\n"
        "__device__ __forceinline__ double mhx_ux_min(double a, double b) { return a < b ? a : b; }\n"
        "__device__ __forceinline__ double mhx_ux_max(double a, double b) { return a > b ? a : b; }\n"
@@ -244,17 +245,17 @@ static std::string generate(const std::vector<UserExpr>& models,
   }
   s << "      default: return bounds_total;\n    }\n  }\n};\n}  // namespace mhx\n"
        "using namespace mhx;\n"
-       "extern \"C\" __global__ __launch_bounds__(512) void mhx_user_logpost(\n"
+       "extern \"C\" __global__ __launch_bounds__(MHX_USER_THREADS) void mhx_user_logpost(\n"
        "    const ProblemDesc* P, const double* theta, int64_t n, double* out, double* parts) {\n"
        "  k_logpost_body<UserSpec>(P, theta, n, out, parts);\n}\n"
-       "extern \"C\" __global__ __launch_bounds__(512) void mhx_user_init(const ProblemDesc* P,\n"
+       "extern \"C\" __global__ __launch_bounds__(MHX_USER_THREADS) void mhx_user_init(const ProblemDesc* P,\n"
        "                                                              ChainState S) {\n"
        "  k_init_body<UserSpec>(P, S);\n}\n"
-       "extern \"C\" __global__ __launch_bounds__(512) void mhx_user_step(\n"
+       "extern \"C\" __global__ __launch_bounds__(MHX_USER_THREADS) void mhx_user_step(\n"
        "    const ProblemDesc* P, ChainState S, const double* L, int per_chain_l, const double* z,\n"
        "    const double* u, const double* T, unsigned char* accepted) {\n"
        "  k_step_injected_body<UserSpec>(P, S, L, per_chain_l, z, u, T, accepted);\n}\n"
-       "extern \"C\" __global__ __launch_bounds__(512, "
+       "extern \"C\" __global__ __launch_bounds__(MHX_USER_THREADS, "
     << min_waves
     << ") void mhx_user_adaptive(\n"
        "    const ProblemDesc* P, ChainState S, RunDesc R, int64_t max_iters, int plain) {\n"
@@ -263,14 +264,14 @@ static std::string generate(const std::vector<UserExpr>& models,
 }
 
 static int build_once(const std::vector<UserExpr>& models, const std::vector<UserExpr>& priors,
-                      bool builtin_fallback, int min_waves, UserProgram* prog,
+                      bool builtin_fallback, const Family& fam, int min_waves, UserProgram* prog,
                       std::string* err) {
   Hiprtc& r = rtc();
   if (!r.ok) {
     *err = "libhiprtc.so could not be loaded: expression models need ROCm's hiprtc";
     return -1;
   }
-  prog->source = generate(models, priors, builtin_fallback, min_waves);
+  prog->source = generate(models, priors, builtin_fallback, min_waves, fam.threads);
   if (const char* dump = getenv("MHX_RTC_DUMP")) {  // the generated translation unit, for study
     if (FILE* fp = fopen(dump, "w")) {
       fputs(prog->source.c_str(), fp);
@@ -287,8 +288,12 @@ static int build_once(const std::vector<UserExpr>& models, const std::vector<Use
     *err = std::string("hiprtcCreateProgram: ") + (r.GetErrorString ? r.GetErrorString(rc) : "?");
     return -1;
   }
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
-  rc = r.CompileProgram(p, 4, opts);
+  // the same family defines the ahead-of-time build of this workgroup shape gets (Makefile)
+  const std::string wpg = "-DMHX_WPG=" + std::to_string(fam.waves_per_group);
+  const std::string famns = "-DMHX_FAMILY=w" + std::to_string(fam.waves_per_group);
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                        wpg.c_str(), famns.c_str()};
+  rc = r.CompileProgram(p, 6, opts);
   size_t ls = 0;
   if (r.GetProgramLogSize(p, &ls) == 0 && ls > 1) {
     prog->log.resize(ls);
@@ -322,12 +327,13 @@ static int build_once(const std::vector<UserExpr>& models, const std::vector<Use
     if (he == hipSuccess)
       he = hipFuncSetAttribute(reinterpret_cast<const void*>(*x.f),
                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)group_lds_bytes());
+                               (int)fam.lds_bytes);
     if (he != hipSuccess) {
       *err = std::string("module function ") + x.n + ": " + hipGetErrorString(he);
       return -1;
     }
   }
+  prog->fam = &fam;
   return 0;
 }
 
@@ -337,38 +343,38 @@ static int build_once(const std::vector<UserExpr>& models, const std::vector<Use
 // controller's own code uses - it is rebuilt for 2 waves per SIMD (256 VGPRs).
 // MHX_RTC_MIN_WAVES=2|4 pins the choice.
 int rtc_build(const std::vector<UserExpr>& models, const std::vector<UserExpr>& priors,
-              bool builtin_fallback, UserProgram* prog, std::string* err) {
+              bool builtin_fallback, const Family& fam, UserProgram* prog, std::string* err) {
   int pinned = 0;
   if (const char* s = getenv("MHX_RTC_MIN_WAVES")) pinned = atoi(s);
   if (pinned == 2 || pinned == 4)
-    return build_once(models, priors, builtin_fallback, pinned, prog, err);
-  int rc = build_once(models, priors, builtin_fallback, 4, prog, err);
+    return build_once(models, priors, builtin_fallback, fam, pinned, prog, err);
+  int rc = build_once(models, priors, builtin_fallback, fam, 4, prog, err);
   if (rc != 0) return rc;
   int scratch = 0;
   if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, prog->f_adaptive) !=
           hipSuccess ||
       scratch <= 128)
     return 0;
-  return build_once(models, priors, builtin_fallback, 2, prog, err);
+  return build_once(models, priors, builtin_fallback, fam, 2, prog, err);
 }
 
-static inline unsigned grid_for(int64_t n) {
-  return (unsigned)((n + kWavesPerGroup - 1) / kWavesPerGroup);
+static inline unsigned grid_for(const UserProgram& p, int64_t n) {
+  return (unsigned)((n + p.fam->waves_per_group - 1) / p.fam->waves_per_group);
 }
 
 hipError_t rtc_launch_logpost(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                               const double* theta, int64_t n, double* out, double* parts) {
   if (n <= 0) return hipSuccess;
   void* args[] = {(void*)&P, (void*)&theta, (void*)&n, (void*)&out, (void*)&parts};
-  return hipModuleLaunchKernel(p.f_logpost, grid_for(n), 1, 1, kThreads, 1, 1,
-                               (unsigned)group_lds_bytes(), st, args, nullptr);
+  return hipModuleLaunchKernel(p.f_logpost, grid_for(p, n), 1, 1, (unsigned)p.fam->threads, 1, 1,
+                               (unsigned)p.fam->lds_bytes, st, args, nullptr);
 }
 hipError_t rtc_launch_init(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                            const ChainState& S) {
   ChainState s = S;
   void* args[] = {(void*)&P, (void*)&s};
-  return hipModuleLaunchKernel(p.f_init, grid_for(S.n_chains), 1, 1, kThreads, 1, 1,
-                               (unsigned)group_lds_bytes(), st, args, nullptr);
+  return hipModuleLaunchKernel(p.f_init, grid_for(p, S.n_chains), 1, 1, (unsigned)p.fam->threads, 1, 1,
+                               (unsigned)p.fam->lds_bytes, st, args, nullptr);
 }
 hipError_t rtc_launch_step_injected(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                                     const ChainState& S, const double* L, int per_chain_l,
@@ -377,8 +383,8 @@ hipError_t rtc_launch_step_injected(const UserProgram& p, hipStream_t st, const 
   ChainState s = S;
   void* args[] = {(void*)&P, (void*)&s, (void*)&L, (void*)&per_chain_l, (void*)&z,
                   (void*)&u, (void*)&T, (void*)&accepted};
-  return hipModuleLaunchKernel(p.f_step, grid_for(S.n_chains), 1, 1, kThreads, 1, 1,
-                               (unsigned)group_lds_bytes(), st, args, nullptr);
+  return hipModuleLaunchKernel(p.f_step, grid_for(p, S.n_chains), 1, 1, (unsigned)p.fam->threads, 1, 1,
+                               (unsigned)p.fam->lds_bytes, st, args, nullptr);
 }
 hipError_t rtc_launch_adaptive(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                                const ChainState& S, const RunDesc& R, int64_t max_iters,
@@ -386,8 +392,8 @@ hipError_t rtc_launch_adaptive(const UserProgram& p, hipStream_t st, const Probl
   ChainState s = S;
   RunDesc r = R;
   void* args[] = {(void*)&P, (void*)&s, (void*)&r, (void*)&max_iters, (void*)&plain};
-  return hipModuleLaunchKernel(p.f_adaptive, grid_for(S.n_chains), 1, 1, kThreads, 1, 1,
-                               (unsigned)group_lds_bytes(), st, args, nullptr);
+  return hipModuleLaunchKernel(p.f_adaptive, grid_for(p, S.n_chains), 1, 1, (unsigned)p.fam->threads, 1, 1,
+                               (unsigned)p.fam->lds_bytes, st, args, nullptr);
 }
 
 }  // namespace mhx

@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 
+#include "mhx_launch.hpp"
 #include "mhx_types.hpp"
 
 namespace mhx {
@@ -26,6 +27,7 @@ struct UserExpr {
 struct UserProgram {
   hipModule_t module = nullptr;
   hipFunction_t f_logpost = nullptr, f_init = nullptr, f_step = nullptr, f_adaptive = nullptr;
+  const Family* fam = nullptr;  // the kernel family (workgroup shape) the module was built for
   std::string source, log;
   ~UserProgram();
 };
@@ -41,7 +43,7 @@ int rtc_prepare_expr(const std::string& expr, const std::vector<std::string>& na
 // functions with ahead-of-time models, so the generic dispatcher must be part of the kernels.
 // Returns 0 or fills *err.
 int rtc_build(const std::vector<UserExpr>& models, const std::vector<UserExpr>& priors,
-              bool builtin_fallback, UserProgram* prog, std::string* err);
+              bool builtin_fallback, const Family& fam, UserProgram* prog, std::string* err);
 
 hipError_t rtc_launch_logpost(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                               const double* theta, int64_t n, double* out, double* parts);

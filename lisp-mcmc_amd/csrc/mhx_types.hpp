@@ -19,13 +19,16 @@
 namespace mhx {
 
 constexpr int kWave = 64;
-#ifndef MHX_WPG
-#define MHX_WPG 8  // tuning knob (4 / 8 / 16 measured in round 1)
-#endif
-constexpr int kWavesPerGroup = MHX_WPG;     // one wave = one chain; a workgroup shares LDS tiles
-constexpr int kThreads = kWave * kWavesPerGroup;
-constexpr int kTilePoints = 2 * kThreads;   // data points per LDS tile (per array): one 16-B
-                                            // LDS-DMA element per thread
+// The device code is compiled in two FAMILIES that differ in the chains (= waves) per workgroup,
+// and with it in the LDS tile (2 * 64 * waves points: one 16-B LDS-DMA element per thread and
+// array):
+//   w8   8 waves, 1024-point tiles, two workgroups per CU: short datasets, few chains
+//   w16 16 waves, 2048-point tiles, one workgroup per CU: half the per-tile fixed cost (barrier,
+//        pipeline prologue), +9 % on BASELINE config 2, -17 % on test.lisp's 334 points
+// The engine picks one per problem (mhx_engine.cpp: choose_family).  Datasets are padded to
+// kPadPoints, a whole number of tiles of either family.
+constexpr int tile_points_of(int waves_per_group) { return 2 * kWave * waves_per_group; }
+constexpr int kPadPoints = tile_points_of(16);
 constexpr int kMaxArrays = 4;               // x, y, w, c
 
 struct FnDesc {
@@ -40,7 +43,7 @@ struct FnDesc {
   const double* w;  // 1/sigma (normal), unused (poisson)
   const double* c;  // -1/2 log(2 pi) - log sigma_i (cutoff only)
   int64_t n;        // points
-  int64_t n_tiles;  // ceil(n / kTilePoints)
+  int64_t n_tiles;  // ceil(n / tile points of the family in use)
   double lik_const; // normal: sum_i(-1/2 log 2pi - log sigma_i); poisson: -sum_i logfact(k_i)
   double xmin, xmax; // range of x over the n points (fast-path preconditions of the models)
   const double* txlo;  // [n_tiles] smallest / largest x of each tile (-inf / +inf when a tile

@@ -1,0 +1,90 @@
+"""The device code exists in two kernel families (8 and 16 chains per workgroup, 1024- and
+2048-point LDS tiles; csrc/mhx_types.hpp).  Which one runs is a performance choice of the engine
+(MHX_FAMILY_WPG pins it) and must not be visible in any result: the per-lane summation order does
+not depend on the tile size, so everything is compared for equality."""
+import os
+
+import numpy as np
+import pytest
+
+import problems as pb
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mhx():
+    import lisp_mcmc_amd
+    return lisp_mcmc_amd
+
+
+def engines(make):
+    out = []
+    for wpg in ("8", "16"):
+        os.environ["MHX_FAMILY_WPG"] = wpg
+        try:
+            out.append(make())
+        finally:
+            os.environ.pop("MHX_FAMILY_WPG", None)
+    return out
+
+
+SPECS = [
+    ("two_peak", lambda: pb.two_peak(n=5000, seed=31)),
+    ("two_peak_short", lambda: pb.two_peak(n=70, seed=32)),
+    ("two_peak_cutoff", lambda: pb.two_peak(n=2049, seed=33, lik=pb.CUTOFF)),
+    ("poisson", lambda: pb.poisson_peaks(n=4100, seed=34)),
+    ("global_fit", lambda: pb.global_fit(n_each=700, n_sets=4, seed=35)),
+    ("lorder", lambda: pb.lorder()),
+]
+
+
+@pytest.mark.parametrize("name,make_spec", SPECS, ids=[s[0] for s in SPECS])
+def test_logposts_and_walks_do_not_depend_on_the_family(mhx, name, make_spec):
+    s = make_spec()
+    C_ = 19  # not a multiple of either workgroup size
+    th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=3)
+
+    def make():
+        e = s.engine(mhx, C_, seed=8)
+        e.init_chains(th0)  # finalises the problem under the pinned family
+        return e
+    a, b = engines(make)
+    th = pb.perturbed(s.theta_star, 40, 0.03, seed=4)
+    ga, pa = a.logpost(th, parts=True)
+    gb, pb_ = b.logpost(th, parts=True)
+    assert np.array_equal(ga, gb, equal_nan=True) and np.array_equal(pa, pb_, equal_nan=True)
+    l0 = np.diag(0.003 * np.abs(s.theta_star) + 1e-6)
+    for e in (a, b):
+        e.adaptive_begin(1300, 10.0, 1, l_matrix=l0)
+        e.adaptive_advance(1 << 40)
+    sa, sb = a.state(), b.state()
+    for k in ("theta", "logpost", "age", "length"):
+        assert np.array_equal(sa[k], sb[k], equal_nan=True), (name, k)
+    assert np.array_equal(a.lmatrix(), b.lmatrix(), equal_nan=True)
+    assert np.array_equal(a.chain_status()[0], b.chain_status()[0])
+    a.close()
+    b.close()
+
+
+def test_expression_kernels_in_both_families(mhx):
+    rng = np.random.default_rng(12)
+    n = 4500
+    x = np.linspace(0, 4, n)
+    sig = rng.uniform(0.05, 0.2, n)
+    y = 2.0 * np.exp(-x / 1.5) + 0.3 + sig * rng.standard_normal(n)
+    text = "(lambda (x &key a tau c &allow-other-keys) (+ c (* a (exp (/ (- x) tau)))))"
+
+    def make():
+        return mhx.walker_create(function=mhx.models.lisp(text), data=[x, y],
+                                 params=[":a", 1.8, ":tau", 1.4, ":c", 0.35], data_error=sig,
+                                 n_chains=5, seed=2)
+    a, b = engines(make)
+    assert a.last_step().prob == b.last_step().prob
+    # exp(-x/tau) overflows once a proposal makes tau slightly negative (a floating-point trap in
+    # the reference too): start from a small :l-matrix instead of diag(params)
+    for w in (a, b):
+        mhx.walker_adaptive_steps_full(w, n=1500, temperature=10, auto=":prob-settle",
+                                       l_matrix=np.diag([0.02, 0.02, 0.01]))
+    assert mhx.walker_get(a, get=":most-likely-params") == mhx.walker_get(b, get=":most-likely-params")
+    assert np.array_equal(a.engine.state()["theta"], b.engine.state()["theta"])
