@@ -24,10 +24,10 @@
 #define MHX_FAMILY w8
 #endif
 #ifndef MHX_PPI
-// data points per lane and inner-loop iteration: 8 iterations per tile in either family (the
-// fully unrolled loop of 16 two-point iterations is more than the unroller accepts, and a rolled
-// loop loses the software pipeline); 2 keeps the pad evaluations of short datasets low (w8)
-#define MHX_PPI (MHX_WPG >= 16 ? 4 : 2)
+// data points per lane and inner-loop iteration.  2 keeps the pad evaluations of short datasets
+// and the register pressure low: with 4 the 16-wave kernels run at the same speed but spill
+// 224 instead of 80 bytes per lane around every likelihood sweep (measured)
+#define MHX_PPI 2
 #endif
 #ifndef MHX_PPI_MASKED
 #define MHX_PPI_MASKED 4  // the same where Gaussian peaks are skipped through run-time branches

@@ -102,70 +102,82 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
         // independent fp64 chains (+5 % on BASELINE config 3).
         constexpr int P = (FAST && model_has_skip<Model>::value && model_peaks<Model>::value > 2)
                               ? MHX_PPI_MASKED : MHX_PPI;
+        // a tile is worked through in sections of at most 8 fully unrolled iterations (more than
+        // that is beyond what the unroller accepts, and a rolled loop would lose the pipeline):
+        // one section per tile in the 8-wave family, one or two in the 16-wave family
         constexpr int NIT = kTilePoints / kWave / P;
-        static_assert(kTilePoints % (kWave * P) == 0, "whole iterations per tile");
-        double x[P], y[P], wv[P], cv[P];
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-          x[i] = tx[i * kWave + l];
-          y[i] = ty[i * kWave + l];
-          wv[i] = 0.0;
-          cv[i] = 0.0;
-          if constexpr (NARR > 2) wv[i] = tw[i * kWave + l];
-          if constexpr (NARR > 3) cv[i] = tc[i * kWave + l];
-        }
+        constexpr int NIN = NIT > 8 ? 8 : NIT;
+        constexpr int NSEC = NIT / NIN;
+        static_assert(kTilePoints % (kWave * P) == 0 && NIT % NIN == 0, "whole sections per tile");
         // points of this tile that are data (the rest are neutral pads): short datasets such as
         // test.lisp's 334 points leave most of their only tile unused
         const int nv = (int)((f.n - gbase) < (int64_t)kTilePoints ? (f.n - gbase) : (int64_t)kTilePoints);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          if (it * P * kWave >= nv) break;  // uniform: one scalar compare per P points
-          double xn[P], yn[P], wn[P], cn[P];
-#pragma unroll
-          for (int i = 0; i < P; ++i) {
-            xn[i] = yn[i] = wn[i] = cn[i] = 0.0;
-            if (it + 1 < NIT) {
-              const int j = ((it + 1) * P + i) * kWave + l;
-              xn[i] = tx[j];
-              yn[i] = ty[j];
-              if constexpr (NARR > 2) wn[i] = tw[j];
-              if constexpr (NARR > 3) cn[i] = tc[j];
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the arithmetic below
-          double m[P];
-          model_eval_n<Model, FAST, P>(prep, x, mask, m);
-          // even points feed acc0, odd points acc1, each in increasing point order: the summation
-          // order the oracle's mirror mode restates
+#pragma unroll 1
+        for (int sec = 0; sec < NSEC; ++sec) {
+          const int sbase = sec * NIN * P * kWave;  // first tile element of this section
+          if (sbase >= nv) break;
+          double x[P], y[P], wv[P], cv[P];
 #pragma unroll
           for (int i = 0; i < P; ++i) {
-            double& acc = (i & 1) ? acc1 : acc0;
-            if constexpr (LIK == MHX_LIK_NORMAL) {
-              // the y array holds y/sigma (host, once): r = y/sigma - m/sigma in one fma
-              const double r = __builtin_fma(-m[i], wv[i], y[i]);
-              acc = __builtin_fma(r, r, acc);
-            } else if constexpr (LIK == MHX_LIK_NORMAL_CUTOFF) {
-              const double r = __builtin_fma(-m[i], wv[i], y[i]);
-              const double tt = __builtin_fma(-0.5 * r, r, cv[i]);
-              acc = acc + (tt > -5000.0 ? tt : -5000.0);  // (max -5000d0 term) M:426
-              // pads carry c = 0, w = 0 -> max(-5000, 0) = 0
-            } else if constexpr (LIK == MHX_LIK_EXPR) {
-              // (funcall log-liklihood-function y (apply fn x params) stddev) M:415: the tiles
-              // hold y and sigma as given; pads masked
-              const double tt = Model::lik_term(y[i], m[i], wv[i]);
-              acc = acc + ((gbase + (it * P + i) * kWave + l) < f.n ? tt : 0.0);
-            } else {
-              // (- (* k (log lambda)) lambda ...) M:383; pads masked (no neutral pad exists)
-              const double tt = __builtin_fma(y[i], mlog(m[i]), -m[i]);
-              acc = acc + ((gbase + (it * P + i) * kWave + l) < f.n ? tt : 0.0);
-            }
+            x[i] = tx[sbase + i * kWave + l];
+            y[i] = ty[sbase + i * kWave + l];
+            wv[i] = 0.0;
+            cv[i] = 0.0;
+            if constexpr (NARR > 2) wv[i] = tw[sbase + i * kWave + l];
+            if constexpr (NARR > 3) cv[i] = tc[sbase + i * kWave + l];
           }
 #pragma unroll
-          for (int i = 0; i < P; ++i) {
-            x[i] = xn[i];
-            y[i] = yn[i];
-            wv[i] = wn[i];
-            cv[i] = cn[i];
+          for (int it = 0; it < NIN; ++it) {
+            if (sbase + it * P * kWave >= nv) break;  // uniform: one scalar compare per P points
+            double xn[P], yn[P], wn[P], cn[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+              xn[i] = yn[i] = wn[i] = cn[i] = 0.0;
+              if (it + 1 < NIN) {
+                const int j = sbase + ((it + 1) * P + i) * kWave + l;
+                xn[i] = tx[j];
+                yn[i] = ty[j];
+                if constexpr (NARR > 2) wn[i] = tw[j];
+                if constexpr (NARR > 3) cn[i] = tc[j];
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the arithmetic below
+            double m[P];
+            model_eval_n<Model, FAST, P>(prep, x, mask, m);
+            // even points feed acc0, odd points acc1, each in increasing point order: the
+            // summation order the oracle's mirror mode restates
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+              double& acc = (i & 1) ? acc1 : acc0;
+              const int64_t gi = gbase + sbase + (it * P + i) * kWave + l;  // index in the dataset
+              (void)gi;
+              if constexpr (LIK == MHX_LIK_NORMAL) {
+                // the y array holds y/sigma (host, once): r = y/sigma - m/sigma in one fma
+                const double r = __builtin_fma(-m[i], wv[i], y[i]);
+                acc = __builtin_fma(r, r, acc);
+              } else if constexpr (LIK == MHX_LIK_NORMAL_CUTOFF) {
+                const double r = __builtin_fma(-m[i], wv[i], y[i]);
+                const double tt = __builtin_fma(-0.5 * r, r, cv[i]);
+                acc = acc + (tt > -5000.0 ? tt : -5000.0);  // (max -5000d0 term) M:426
+                // pads carry c = 0, w = 0 -> max(-5000, 0) = 0
+              } else if constexpr (LIK == MHX_LIK_EXPR) {
+                // (funcall log-liklihood-function y (apply fn x params) stddev) M:415: the tiles
+                // hold y and sigma as given; pads masked
+                const double tt = Model::lik_term(y[i], m[i], wv[i]);
+                acc = acc + (gi < f.n ? tt : 0.0);
+              } else {
+                // (- (* k (log lambda)) lambda ...) M:383; pads masked (no neutral pad exists)
+                const double tt = __builtin_fma(y[i], mlog(m[i]), -m[i]);
+                acc = acc + (gi < f.n ? tt : 0.0);
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+              x[i] = xn[i];
+              y[i] = yn[i];
+              wv[i] = wn[i];
+              cv[i] = cn[i];
+            }
           }
         }
       };
