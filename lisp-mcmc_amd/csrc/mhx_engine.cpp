@@ -189,6 +189,10 @@ int finalize_problem(mhx_engine* e) {
     f.txlo = D.txlo.p;
     f.txhi = D.txhi.p;
     f.n_tiles = (int64_t)nt;
+    // the one tile stays in LDS (sweep).  Measured (tools/ab_tree.sh, test.lisp's shape): +9 %
+    // with one chain, -5 % with 512 and -15 % with 2048 chains: only the single-walker case, the
+    // reference's own way of working, gets it
+    f.solo = (e->P.K == 1 && nt == 1 && e->cfg.n_chains <= e->fam->waves_per_group) ? 1 : 0;
   }
   // expression models / prior bodies: assign slots, compile once per distinct problem text
   std::vector<UserExpr> models, priors;

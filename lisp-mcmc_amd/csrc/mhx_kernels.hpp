@@ -25,7 +25,14 @@ struct GroupLds {
   double tiles[2][kMaxArrays][kTilePoints];        // 64 KiB
   double prop[kWavesPerGroup][MHX_MAX_PARAMS];     // proposal theta' of each wave, 4 KiB
   double prm[kWavesPerGroup][MHX_MAX_FN_PARAMS + 4];
+  int resident;  // 1: tile 0 of the problem's only function sits in tiles[0] (FnDesc::solo)
 };
+
+// every kernel that sweeps starts with this (LDS comes up uninitialised)
+__device__ __forceinline__ void lds_begin(GroupLds& lds) {
+  if (threadIdx.x == 0) lds.resident = 0;
+  __syncthreads();
+}
 
 // ------------------------------------------------------------------------------------------
 // LDS tile pipeline + per-lane accumulation of one function's likelihood sum
@@ -73,11 +80,21 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
   double acc0 = 0.0, acc1 = 0.0;
   unsigned tile_masks = ~0u;  // lane i: which peaks tile (t & ~63) + i needs (PeaksModel::tile_mask)
   if (nt == 0) return 0.0;
-  tile_dma<NARR>(f, 0, lds, 0, w);
-  // An LDS-DMA is ordered for the readers only by the ISSUING wave's vmcnt wait followed by a
-  // barrier: written out here, never left to the compiler's handling of __syncthreads().
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // A problem with ONE function of ONE tile (test.lisp's 334 points) walked by a single
+  // workgroup keeps that tile in LDS for the whole launch: after the first sweep there is no DMA
+  // and no barrier left in here, which takes the L2 round trip out of every step of a
+  // latency-bound walk (+9 % on a single chain; with hundreds of chains it measured slower, so
+  // the engine sets FnDesc::solo only there).
+  const bool solo = f.solo != 0;
+  const bool have = solo && __builtin_amdgcn_readfirstlane(lds.resident) != 0;
+  if (!have) {
+    tile_dma<NARR>(f, 0, lds, 0, w);
+    // An LDS-DMA is ordered for the readers only by the ISSUING wave's vmcnt wait followed by a
+    // barrier: written out here, never left to the compiler's handling of __syncthreads().
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (solo && threadIdx.x == 0) lds.resident = 1;
+    __syncthreads();
+  }
   for (int64_t t = 0; t < nt; ++t) {
     const int buf = (int)(t & 1);
     // buffer buf^1 was last read in iteration t-1, which every wave left through the barrier
@@ -206,8 +223,10 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
         tile_body(CMask<~0u>{});
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of tile t+1 has landed
-    __syncthreads();                                   // ... and so has everybody else's
+    if (!solo) {  // (a resident tile is never overwritten: nothing to wait for)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of tile t+1 has landed
+      __syncthreads();                                   // ... and so has everybody else's
+    }
   }
   return wave_sum(acc0 + acc1);
 }
@@ -562,6 +581,7 @@ __device__ __forceinline__ void k_logpost_body(const ProblemDesc* __restrict__ P
                                                double* __restrict__ out,
                                                double* __restrict__ parts) {
   GroupLds& lds = *reinterpret_cast<GroupLds*>(mhx_lds_raw);
+  lds_begin(lds);
   const ProblemDesc& P = *Pp;
   const int w = wave_in_group(), l = lane_id(), d = P.d;
   const int64_t c = (int64_t)blockIdx.x * kWavesPerGroup + w;
@@ -594,6 +614,7 @@ __global__ __launch_bounds__(kThreads) void k_init(const ProblemDesc* __restrict
 template <class Spec>
 __device__ __forceinline__ void k_init_body(const ProblemDesc* __restrict__ Pp, ChainState S) {
   GroupLds& lds = *reinterpret_cast<GroupLds*>(mhx_lds_raw);
+  lds_begin(lds);
   const ProblemDesc& P = *Pp;
   const int w = wave_in_group(), l = lane_id(), d = P.d;
   const int64_t c = (int64_t)blockIdx.x * kWavesPerGroup + w;
@@ -718,6 +739,7 @@ __device__ __forceinline__ void k_step_injected_body(
     int per_chain_l, const double* __restrict__ z, const double* __restrict__ u,
     const double* __restrict__ T, unsigned char* __restrict__ accepted) {
   GroupLds& lds = *reinterpret_cast<GroupLds*>(mhx_lds_raw);
+  lds_begin(lds);
   const ProblemDesc& P = *Pp;
   const int w = wave_in_group(), l = lane_id(), d = P.d;
   const int64_t c = (int64_t)blockIdx.x * kWavesPerGroup + w;
@@ -770,6 +792,7 @@ template <class Spec>
 __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ Pp, ChainState S,
                                                 RunDesc R, int64_t max_iters, int plain) {
   GroupLds& lds = *reinterpret_cast<GroupLds*>(mhx_lds_raw);
+  lds_begin(lds);
   const ProblemDesc& P = *Pp;
   const int w = wave_in_group(), l = lane_id(), d = P.d;
   const int64_t c = (int64_t)blockIdx.x * kWavesPerGroup + w;
@@ -796,7 +819,8 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
       if (r.loop_i >= R.n) {  // end test of the do loop, M:904
         r.status = MHX_CHAIN_DONE;
         running = false;
-      } else if (__builtin_amdgcn_readfirstlane(*(volatile const int*)R.stop_flag)) {
+      } else if ((it & 15) == 0 &&  // looked at every 16th iteration: one L2 round trip less
+                 __builtin_amdgcn_readfirstlane(*(volatile const int*)R.stop_flag)) {
         r.status = MHX_CHAIN_STOPPED;  // mfit-walker-estop
         running = false;
       }
@@ -910,6 +934,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
 __global__ __launch_bounds__(kThreads) void k_initial_l(ChainState S, RunDesc R, int have_l,
                                                         double T0) {
   GroupLds& lds = *reinterpret_cast<GroupLds*>(mhx_lds_raw);
+  lds_begin(lds);
   const int w = wave_in_group(), l = lane_id(), d = S.d;
   const int64_t c = (int64_t)blockIdx.x * kWavesPerGroup + w;
   if (c >= S.n_chains) return;

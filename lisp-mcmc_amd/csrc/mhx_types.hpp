@@ -49,7 +49,7 @@ struct FnDesc {
   const double* txlo;  // [n_tiles] smallest / largest x of each tile (-inf / +inf when a tile
   const double* txhi;  // holds a non-finite x): what tile-level peak skipping tests against
   int32_t tile_skip;   // 0: evaluate every peak for every point (MHX_NO_TILE_SKIP=1)
-  int32_t pad_;
+  int32_t solo;        // 1: the problem's only function and a single tile - it stays in LDS
   int32_t user_slot;  // >= 0: index of the run-time compiled expression model (MHX_MODEL_EXPR)
   int32_t prior_slot; // >= 0: index of the run-time compiled prior body, else -1
 };
