@@ -145,3 +145,34 @@ def test_c5_per_gpu_share_65536_chains(mhx, orc, c2):
     w.adaptive_advance(n_it)
     assert np.array_equal(sb["theta"][40001], w.last()[0])
     big.close()
+
+
+def test_c2_complete_default_run_4096_chains(mhx, c2):
+    """(walker-adaptive-steps w) with its default n = 30000 on every one of the 4096 chains of
+    BASELINE config 2: annealing, L-matrix adaptation and the automatic shut-down all the way to
+    the end of the do loop.  Every chain must finish (none trapped), sit at the posterior mode
+    within its width, and sample with a healthy acceptance rate."""
+    C_ = 4096
+    rng = np.random.Generator(np.random.Philox(key=7))
+    th0 = c2.theta_star[None, :] * (1.0 + 0.01 * rng.standard_normal((C_, c2.d)))
+    e = c2.engine(mhx, C_, seed=77)
+    e.init_chains(th0)
+    e.adaptive_steps(30000)
+    st, _ = e.chain_status()
+    assert (st == mhx.capi.CHAIN_DONE).all(), np.bincount(st)
+    s = e.state()
+    assert np.isfinite(s["logpost"]).all()
+    # posterior widths at 1e5 points are ~1e-3 relative: the chains agree with each other and
+    # with the generating parameters far inside the 50 % bounds box
+    best = s["best_theta"] if "best_theta" in s else s["theta"]
+    rel = np.abs(np.median(best, axis=0) / c2.theta_star - 1.0)
+    assert (rel < 0.02).all(), rel
+    spread = np.std(s["theta"], axis=0) / np.abs(c2.theta_star)
+    assert (spread < 0.02).all(), spread
+    acc = e.acceptance(1000)
+    assert 0.1 < float(np.median(acc)) < 0.6, float(np.median(acc))
+    # every chain used the whole loop or shut itself down through :prob-settle (M:905-917), which
+    # jumps to the last (tail) iterations: ages of 7000-16000 are typical here
+    assert (s["age"] > 2000).all() and (s["age"] <= 30001).all()
+    assert (s["age"] < 30001).any()
+    e.close()
