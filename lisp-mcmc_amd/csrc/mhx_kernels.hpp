@@ -25,12 +25,14 @@ struct GroupLds {
   double tiles[2][kMaxArrays][kTilePoints];        // 64 KiB
   double prop[kWavesPerGroup][MHX_MAX_PARAMS];     // proposal theta' of each wave, 4 KiB
   double prm[kWavesPerGroup][MHX_MAX_FN_PARAMS + 4];
+  double logtab[256];  // kLogTab, for tlog() in the Poisson sweep: 2 KiB
   int resident;  // 1: tile 0 of the problem's only function sits in tiles[0] (FnDesc::solo)
 };
 
 // every kernel that sweeps starts with this (LDS comes up uninitialised)
 __device__ __forceinline__ void lds_begin(GroupLds& lds) {
   if (threadIdx.x == 0) lds.resident = 0;
+  if (threadIdx.x < 256) lds.logtab[threadIdx.x] = kLogTab[threadIdx.x >> 1][threadIdx.x & 1];
   __syncthreads();
 }
 
@@ -184,7 +186,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
                 acc = acc + (gi < f.n ? tt : 0.0);
               } else {
                 // (- (* k (log lambda)) lambda ...) M:383; pads masked (no neutral pad exists)
-                const double tt = __builtin_fma(y[i], mlog(m[i]), -m[i]);
+                const double tt = __builtin_fma(y[i], tlog(m[i], (lds_cdptr_t)lds.logtab), -m[i]);
                 acc = acc + (gi < f.n ? tt : 0.0);
               }
             }
