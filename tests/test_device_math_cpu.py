@@ -1,0 +1,94 @@
+"""CPU checks of device math that has no oracle twin: the table-driven logarithm of the Poisson
+sweep (tlog, csrc/mhx_device.hpp).  The table is parsed out of the header, its two defining
+properties are verified with mpmath, and a C restatement of the algorithm (same operations, C99
+fma) is measured against the 80-bit logl."""
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = os.path.join(ROOT, "lisp-mcmc_amd", "csrc", "mhx_device.hpp")
+
+
+def table_text():
+    src = open(HDR).read()
+    m = re.search(r"kLogTab\[128\]\[2\] = \{(.*?)\n\};", src, re.S)
+    assert m, "kLogTab not found"
+    return m.group(1)
+
+
+def test_log_table_properties():
+    mp = pytest.importorskip("mpmath")
+    mp.mp.prec = 200
+    rows = re.findall(r"\{(-?0x[0-9a-f.]+p[+-]\d+), (-?0x[0-9a-f.]+p[+-]\d+)\}", table_text())
+    assert len(rows) == 128
+    G = mp.mpf(2) ** -43
+    for i, (a, b) in enumerate(rows):
+        invc, logc = float.fromhex(a), float.fromhex(b)
+        assert mp.mpf(logc) / G == mp.nint(mp.mpf(logc) / G), i      # k ln2_hi + log c is exact
+        assert abs(mp.log(1 / mp.mpf(invc)) - mp.mpf(logc)) < mp.mpf(2) ** -67, i
+        # c_i sits inside its subinterval of [0.6875, 1.375)
+        lo = 0.6875 + i * 2.0 ** -8 if i < 80 else 1.0 + (i - 80) * 2.0 ** -7
+        hi = lo + (2.0 ** -8 if i < 80 else 2.0 ** -7)
+        assert lo < 1.0 / invc < hi, i
+
+
+C_SRC = r'''
+#include <math.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+static const double T[128][2] = {
+%s
+};
+static double tlog(double x) {
+  const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
+  const double A1 = 0x1.5555555555555p-2, A3 = 0x1.999999999999ap-3, A4 = -0x1.5555555555555p-3;
+  uint64_t b; memcpy(&b, &x, 8);
+  uint32_t hx = (uint32_t)(b >> 32), lx = (uint32_t)b;
+  uint32_t th = hx - 0x3FE60000u;
+  int i = (int)((th >> 13) & 127u);
+  int k = (int32_t)th >> 20;
+  uint32_t zh = hx - (th & 0xFFF00000u);
+  uint64_t zb = ((uint64_t)zh << 32) | lx; double z; memcpy(&z, &zb, 8);
+  double invc = T[i][0], logc = T[i][1];
+  double r = fma(z, invc, -1.0), kd = (double)k;
+  double w = fma(kd, Ln2hi, logc);
+  double hi = w + r;
+  double lo = fma(kd, Ln2lo, (w - hi) + r);
+  double r2 = r * r;
+  double p1 = fma(r, A4, A3), p2 = fma(r, -0.25, A1);
+  double p3 = fma(r2, p1, p2);
+  double t = fma(r2, -0.5, lo);
+  return fma(r * r2, p3, t) + hi;
+}
+int main(void) {
+  double maxu = 0; srand48(3);
+  for (long n = 0; n < 4000000; ++n) {
+    double x; int m = n %% 4;
+    if (m == 0) x = exp((drand48() * 2 - 1) * 700);
+    else if (m == 1) x = drand48() * 200 + 1e-3;
+    else if (m == 2) x = 0.5 + drand48() * 1.5;
+    else x = ldexp(0.6875 + drand48() * 0.6875, (int)(drand48() * 40) - 20);
+    if (fabs(x - 1.0) < 0.0625) continue;   /* the device sends these through mlog() */
+    long double ref = logl((long double)x);
+    double u = fabs((double)((long double)tlog(x) - ref)) / ldexp(1.0, ilogb((double)ref) - 52);
+    if (u > maxu) maxu = u;
+  }
+  printf("%%.4f\n", maxu);
+  return 0;
+}
+'''
+
+
+def test_table_log_stays_below_one_ulp():
+    d = tempfile.mkdtemp()
+    c, exe = os.path.join(d, "t.c"), os.path.join(d, "t")
+    open(c, "w").write(C_SRC % table_text())
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, c, "-lm"])
+    worst = float(subprocess.check_output([exe]).decode())
+    assert worst < 0.75, worst
