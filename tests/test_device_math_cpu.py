@@ -92,3 +92,52 @@ def test_table_log_stays_below_one_ulp():
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, c, "-lm"])
     worst = float(subprocess.check_output([exe]).decode())
     assert worst < 0.75, worst
+
+
+GEXP_SRC = r'''
+#include <math.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+/* gexp() of csrc/mhx_device.hpp (the exp of user expressions), with C99 fma and a saturating
+   conversion like v_cvt_i32_f64 */
+static int sat_i32(double v) { return v >= 2147483647.0 ? 2147483647 : (v <= -2147483648.0 ? (-2147483647 - 1) : (int)v); }
+static double gexp(double x) {
+  const double MAGIC = 0x1.8p52, L2E_HI = 0x1.71547652b82fep+0, L2E_LO = 0x1.777d0ffda0d24p-56;
+  const double c[12] = {%s};
+  double kd = fma(x, L2E_HI, MAGIC), kf = kd - MAGIC;
+  double f = fma(x, L2E_LO, fma(x, L2E_HI, -kf));
+  double p = c[0];
+  for (int i = 1; i < 12; ++i) p = fma(p, f, c[i]);
+  return ldexp(p, sat_i32(kf));
+}
+int main(void) {
+  double maxu = 0; srand48(1);
+  for (long n = 0; n < 4000000; ++n) {
+    double x = (drand48() * 2 - 1) * (n %% 3 == 0 ? 708.0 : (n %% 3 == 1 ? 30.0 : 1.0));
+    long double r = expl((long double)x);
+    double u = fabs((double)(((long double)gexp(x) - r) / r)) / 0x1p-52;
+    if (u > maxu) maxu = u;
+  }
+  int ok = gexp(710.0) == INFINITY && gexp(-746.0) == 0.0 && gexp(0.0) == 1.0 && isnan(gexp(NAN))
+           && !isfinite(gexp(1e300)) /* inf or nan, never a finite number */;
+  printf("%%.4f %%d\n", maxu, ok);
+  return 0;
+}
+'''
+
+
+def test_expression_exp_stays_below_one_ulp():
+    src = open(HDR).read()
+    body = src[src.index("double gexp(double x)"):]
+    body = body[:body.index("return ldexp")]
+    coefs = [re.search(r"double p = (0x[0-9a-f.]+p[+-]\d+);", body).group(1)]
+    coefs += re.findall(r"__builtin_fma\(p, f, ([0-9a-fx.p+-]+)\);", body)
+    assert len(coefs) == 12 and coefs[-1] == "1.0", coefs
+    d = tempfile.mkdtemp()
+    c, exe = os.path.join(d, "g.c"), os.path.join(d, "g")
+    open(c, "w").write(GEXP_SRC % ", ".join(coefs))
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, c, "-lm"])
+    worst, ok = subprocess.check_output([exe]).decode().split()
+    assert float(worst) < 1.0 and ok == "1", (worst, ok)
