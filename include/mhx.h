@@ -285,6 +285,13 @@ int mhx_get_pooled(mhx_engine* e, double* stats, double* L_pool, int32_t* valid,
 /* Total chain-steps taken by this engine since creation (all chains). */
 int mhx_get_counters(mhx_engine* e, uint64_t* chain_steps, uint64_t* kernel_launches);
 
+/* Which kernels serve the current problem, for logs and benchmarks: "w16/gauss22_normal" (an
+ * ahead-of-time specialisation of the 16-chains-per-workgroup family), "w8/generic", or
+ * "w16/rtc[PeaksModel<2, 3, false>:normal]" (compiled at run time, one entry per function).
+ * Finalises the problem like mhx_init_chains does; NULL (and mhx_last_error) if that fails.
+ * The string lives until the problem is changed or the engine destroyed. */
+const char* mhx_kernel_name(mhx_engine* e);
+
 /* Timing of the step kernel on the engine's own stream (HIP events): average
  * milliseconds per launch and launches since the last reset. */
 int mhx_kernel_timing(mhx_engine* e, int reset, double* avg_ms, uint64_t* launches,

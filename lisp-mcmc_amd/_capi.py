@@ -79,6 +79,7 @@ SIGNATURES = {
     "mhx_walker_modify": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
     "mhx_get_pooled": (C.c_int, [C.c_void_p, f64p, f64p, i32p, u64p]),
     "mhx_get_counters": (C.c_int, [C.c_void_p, u64p, u64p]),
+    "mhx_kernel_name": (C.c_char_p, [C.c_void_p]),
     "mhx_kernel_timing": (C.c_int, [C.c_void_p, C.c_int, f64p, u64p, f64p]),
 }
 

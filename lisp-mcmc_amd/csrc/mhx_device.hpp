@@ -731,10 +731,18 @@ template <class M>
 struct model_has_skip<M, decltype((void)M::kHasSkip, void())> {
   static constexpr bool value = M::kHasSkip;
 };
+// (a model that declares kHasFast - even as false, like the Lorentzian peaks - has the templated
+// eval<FAST>)
+template <class M, class = void>
+struct model_eval_templated { static constexpr bool value = false; };
+template <class M>
+struct model_eval_templated<M, decltype((void)M::kHasFast, void())> {
+  static constexpr bool value = true;
+};
 template <class M, bool FAST>
 __device__ __forceinline__ double model_eval(const typename M::Prep& p, double x,
                                              unsigned mask = ~0u) {
-  if constexpr (model_has_fast<M>::value) {
+  if constexpr (model_eval_templated<M>::value) {
     if constexpr (model_has_skip<M>::value)
       return M::template eval<FAST>(p, x, mask);
     else

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <set>
 #include <sstream>
 
@@ -189,6 +191,10 @@ static std::string generate(const std::vector<UserExpr>& models,
   for (size_t m = 0; m < models.size(); ++m) {
     const UserExpr& u = models[m];
     const int np = (int)u.names.size();
+    if (!u.builtin.empty()) {  // an ahead-of-time model struct: only named, nothing to define
+      s << "using UserModel" << m << " = " << u.builtin << ";\n";
+      continue;
+    }
     s << "struct UserModel" << m << " {\n"
       << "  struct Prep { double p[" << (np > 0 ? np : 1) << "]; };\n"
       << "  template <class PF>\n"
@@ -218,7 +224,11 @@ static std::string generate(const std::vector<UserExpr>& models,
                                    "MHX_LIK_EXPR"};
   for (size_t m = 0; m < models.size(); ++m) {
     const int lik = models[m].lik;
-    if (lik >= 0 && lik <= 3)
+    if (!models[m].builtin.empty() && lik >= 0 && lik <= 2)
+      // the whole FixedSpec: fast-path vote, tile-level peak skipping, parameters in SGPRs
+      s << "      case " << m << ": return FixedSpec<UserModel" << m << ", " << kLikName[lik]
+        << ">::loglik(f, pf, active, lds, scratch);\n";
+    else if (lik >= 0 && lik <= 3)
       s << "      case " << m << ": return GenericSpec::one_lik<UserModel" << m << ", "
         << kLikName[lik] << ">(f, pf, active, lds);\n";
     else
@@ -358,6 +368,25 @@ int rtc_build(const std::vector<UserExpr>& models, const std::vector<UserExpr>& 
       scratch <= 128)
     return 0;
   return build_once(models, priors, builtin_fallback, fam, 2, prog, err);
+}
+
+std::shared_ptr<UserProgram> rtc_get(const std::vector<UserExpr>& models,
+                                     const std::vector<UserExpr>& priors, bool builtin_fallback,
+                                     const Family& fam, std::string* err) {
+  static std::mutex mu;
+  static std::map<std::string, std::weak_ptr<UserProgram>> cache;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const std::string key = "dev" + std::to_string(dev) + "|" +
+                          generate(models, priors, builtin_fallback, 4, fam.threads);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it != cache.end())
+    if (std::shared_ptr<UserProgram> hit = it->second.lock()) return hit;
+  std::shared_ptr<UserProgram> prog(new UserProgram());
+  if (rtc_build(models, priors, builtin_fallback, fam, prog.get(), err) != 0) return nullptr;
+  cache[key] = prog;
+  return prog;
 }
 
 static inline unsigned grid_for(const UserProgram& p, int64_t n) {

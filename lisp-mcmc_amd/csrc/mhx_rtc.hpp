@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -20,6 +21,9 @@ struct UserExpr {
   std::string expr;                // validated, identifiers already rewritten
   std::vector<std::string> names;  // as given by the caller
   std::vector<int> index;
+  std::string builtin;   // models: non-empty = the C++ type of an ahead-of-time model struct
+                         // ("PeaksModel<1, 3, false>"): no expression, the function is only
+                         // given its own compile-time specialisation
   int lik = -1;          // models: the function's likelihood kind (-1: dispatch at run time)
   std::string lik_expr;  // models with MHX_LIK_EXPR: the per-point term over y, model, error
 };
@@ -44,6 +48,11 @@ int rtc_prepare_expr(const std::string& expr, const std::vector<std::string>& na
 // Returns 0 or fills *err.
 int rtc_build(const std::vector<UserExpr>& models, const std::vector<UserExpr>& priors,
               bool builtin_fallback, const Family& fam, UserProgram* prog, std::string* err);
+// The same through a process-wide cache (keyed by device and generated source): engines that
+// describe the same problem share one compiled module.  Returns nullptr and fills *err on error.
+std::shared_ptr<UserProgram> rtc_get(const std::vector<UserExpr>& models,
+                                     const std::vector<UserExpr>& priors, bool builtin_fallback,
+                                     const Family& fam, std::string* err);
 
 hipError_t rtc_launch_logpost(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                               const double* theta, int64_t n, double* out, double* parts);

@@ -244,6 +244,13 @@ class Engine:
         capi.check(capi.lib().mhx_get_counters(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def kernel_name(self):
+        """which kernels serve the problem: 'w16/gauss22_normal', 'w8/rtc[expr:normal]', ..."""
+        r = capi.lib().mhx_kernel_name(self._h)
+        if r is None:
+            raise capi.MhxError(capi.ESTATE, capi.lib().mhx_last_error().decode("utf-8", "replace"))
+        return r.decode()
+
     def kernel_timing(self, reset=False):
         avg, tot, n = C.c_double(0), C.c_double(0), C.c_uint64(0)
         capi.check(capi.lib().mhx_kernel_timing(self._h, int(reset), C.byref(avg), C.byref(n),

@@ -104,6 +104,7 @@ library, or without a gfx950 device, walker-create signals MHX-ERROR."
   (e :pointer) (chain :int64) (take :int) (l-out :pointer) (status :pointer) (n-forward :pointer))
 (cffi:defcfun ("mhx_get_counters" %mhx-get-counters) :int
   (e :pointer) (chain-steps :pointer) (kernel-launches :pointer))
+(cffi:defcfun ("mhx_kernel_name" %mhx-kernel-name) :string (e :pointer))
 (cffi:defcfun ("mhx_kernel_timing" %mhx-kernel-timing) :int
   (e :pointer) (reset :int) (avg-ms :pointer) (launches :pointer) (total-ms :pointer))
 

@@ -1,0 +1,118 @@
+"""Problems without an ahead-of-time kernel are compiled at run time (hiprtc) with one
+compile-time specialisation per function - expression or enumerated model - instead of running on
+the run-time-dispatched generic kernels.  Both must agree with the oracle; the specialised ones
+must really be in use; the generic ones stay reachable."""
+import os
+
+import numpy as np
+import pytest
+
+import problems as pb
+
+pytestmark = pytest.mark.gpu
+REL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def mhx():
+    import lisp_mcmc_amd
+    return lisp_mcmc_amd
+
+
+def three_peaks(n=6000, seed=5, model=pb.GAUSS, lik=pb.NORMAL):
+    rng = np.random.default_rng(seed)
+    th = np.array([0.5, 0.3, 1.0, 0.25, 0.04, 0.7, 0.5, 0.06, 0.9, 0.8, 0.05])
+    x = np.linspace(0.0, 1.0, n)
+    f = pb.model_eval_np(model, (2, 3), th, x)
+    s = pb.Spec(11)
+    lo, hi = np.minimum(th * 0.5, th * 1.5), np.maximum(th * 0.5, th * 1.5)
+    if lik == pb.POISSON:
+        s.add(model, (2, 3), range(11), x, rng.poisson(40 * f).astype(float), None, lik,
+              (list(range(11)), lo, hi))
+        th = th.copy()
+        th[[0, 1, 2, 5, 8]] *= 40
+        s.bounds[0] = (list(range(11)), np.minimum(th * 0.5, th * 1.5), np.maximum(th * 0.5, th * 1.5))
+    else:
+        sig = rng.uniform(0.05, 0.15, n)
+        s.add(model, (2, 3), range(11), x, f + sig * rng.standard_normal(n), sig, lik,
+              (list(range(11)), lo, hi))
+    s.theta_star = th
+    return s
+
+
+CASES = [("gauss_normal", pb.GAUSS, pb.NORMAL), ("gauss_cutoff", pb.GAUSS, pb.CUTOFF),
+         ("gauss_poisson", pb.GAUSS, pb.POISSON), ("lorentz_normal", pb.LORENTZ, pb.NORMAL)]
+
+
+@pytest.mark.parametrize("name,model,lik", CASES, ids=[c[0] for c in CASES])
+def test_specialised_and_generic_kernels_agree_with_the_oracle(mhx, orc, name, model, lik):
+    s = three_peaks(model=model, lik=lik)
+    op = s.oracle(orc)
+    spec = s.engine(mhx, 4)
+    assert "rtc[PeaksModel<2, 3, %s>" % ("true" if model == pb.LORENTZ else "false") in spec.kernel_name()
+    os.environ["MHX_NO_RTC_SPECIALISE"] = "1"
+    try:
+        gen = s.engine(mhx, 4)
+        assert gen.kernel_name().endswith("/generic")
+    finally:
+        os.environ.pop("MHX_NO_RTC_SPECIALISE")
+    th = pb.perturbed(s.theta_star, 24, 0.02, seed=3)
+    th[5] = s.theta_star * 1.6  # outside the bounds box
+    a, pa = spec.logpost(th, parts=True)
+    b, pb_ = gen.logpost(th, parts=True)
+    for i in range(len(th)):
+        ref, rp = op.logpost(th[i], parts=True)
+        tol = REL * op.abs_terms(th[i])
+        assert abs(pa[i, 0] - rp[0]) <= tol and abs(pb_[i, 0] - rp[0]) <= tol, (name, i)
+        nv = int(((th[i] <= s.bounds[0][1]) | (th[i] >= s.bounds[0][2])).sum())
+        assert abs(pa[i, 1] - rp[1]) <= 1e-5 * max(1, nv) and pa[i, 1] == pb_[i, 1]
+    spec.close()
+    gen.close()
+
+
+def test_specialised_walk_matches_the_oracle_controller(mhx, orc):
+    """whole walker-adaptive-steps runs on a specialised kernel: loop index, age and the
+    positions agree with the oracle (same proposals; accept tests could differ only inside the
+    1e-12 band between the two log-posteriors)"""
+    s = three_peaks(n=900, seed=8)
+    op = s.oracle(orc)
+    C_, n = 5, 1400
+    e = s.engine(mhx, C_, seed=4)
+    assert "rtc[" in e.kernel_name()
+    th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=9)
+    e.init_chains(th0)
+    e.adaptive_begin(n, 10.0, 1)
+    e.adaptive_advance(1 << 40)
+    st = e.state()
+    same = 0
+    for c in range(C_):
+        w = orc.Walker(op, th0[c])
+        w.adaptive_begin(n, 10.0, 1, seed=4, chain_id=c)
+        w.adaptive_advance(1 << 40)
+        assert st["age"][c] == w.age
+        same += int(np.array_equal(st["theta"][c], w.last()[0]))
+    assert same >= C_ - 1
+    e.close()
+
+
+def test_mixed_problem_every_function_specialised(mhx, orc):
+    """a global fit mixing enumerated models with different shapes: one kernel, one
+    specialisation per function"""
+    rng = np.random.default_rng(2)
+    x1, x2 = np.linspace(0, 1, 1500), np.linspace(0, 2, 700)
+    th = np.array([0.4, 1.2, 0.5, 0.07, 0.3, 1.5, 0.8])   # bg A mu w | c0 c1 c2
+    s = pb.Spec(7)
+    sig1, sig2 = np.full(1500, 0.1), np.full(700, 0.2)
+    y1 = pb.model_eval_np(pb.GAUSS, (1, 1), th[:4], x1) + 0.1 * rng.standard_normal(1500)
+    y2 = pb.model_eval_np(pb.POLY, (), th[4:], x2) + 0.2 * rng.standard_normal(700)
+    s.add(pb.GAUSS, (1, 1), [0, 1, 2, 3], x1, y1, sig1, pb.NORMAL)
+    s.add(pb.POLY, (), [4, 5, 6], x2, y2, sig2, pb.NORMAL)
+    s.theta_star = th
+    e = s.engine(mhx, 3)
+    assert e.kernel_name().endswith("rtc[PeaksModel<1, 1, false>:normal, PolyModel<3>:normal]")
+    op = s.oracle(orc)
+    t = pb.perturbed(th, 9, 0.03, seed=1)
+    got = e.logpost(t)
+    for i in range(len(t)):
+        assert abs(got[i] - op.logpost(t[i])) <= REL * op.abs_terms(t[i])
+    e.close()
