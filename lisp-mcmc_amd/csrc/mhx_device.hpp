@@ -862,10 +862,17 @@ struct SinusoidModel {
 
 struct PVoigt2Model {
   // per peak: u = x*iw + c (c = -mu*iw); Lorentzian eta/(1+u^2) by frcp; Gaussian
-  // (1-eta) exp(-u^2) = (1-eta) 2^(-(u g)^2), g = sqrt(log2 e)
-  struct Prep { double A, b0, b1, c1, iw1, eta1, om1, c2p, iw2, eta2, om2, rho, c2; };
+  // (1-eta) exp(-u^2) = (1-eta) 2^(-t^2), t = x*(iw g) + c g, g = sqrt(log2 e).  Fast path (the
+  // low-dword exponent trick of mexp2_negsq) when |t| < 46000 over the dataset's x range.
+  static constexpr bool kHasFast = true;
+  struct Prep {
+    double A, b0, b1, c1, iw1, eta1, om1, c2p, iw2, eta2, om2, rho, c2;
+    double g1c, g1w, g2c, g2w;  // the same lines scaled by g (VGPR-pinned constants of the fma)
+    Exp2K K;
+    bool fast;
+  };
   template <class PF>
-  static __device__ __forceinline__ Prep prepare(PF pf, const FnDesc&) {
+  static __device__ __forceinline__ Prep prepare(PF pf, const FnDesc& fn) {
     Prep p;
     p.A = uniform_f64(pf(0)); p.b0 = uniform_f64(pf(1)); p.b1 = uniform_f64(pf(2));
     const double iw1 = 1.0 / pf(4), iw2 = 1.0 / pf(7);
@@ -873,11 +880,29 @@ struct PVoigt2Model {
     p.iw2 = uniform_f64(iw2); p.c2p = uniform_f64(-pf(6) * iw2); p.eta2 = uniform_f64(pf(8));
     p.om1 = uniform_f64(1.0 - pf(5)); p.om2 = uniform_f64(1.0 - pf(8));
     p.rho = uniform_f64(pf(9)); p.c2 = uniform_f64(pf(10));
+    p.g1w = uniform_f64(p.iw1 * kSqrtLog2e); p.g2w = uniform_f64(p.iw2 * kSqrtLog2e);
+    double a = p.c1 * kSqrtLog2e, b = p.c2p * kSqrtLog2e;
+    asm volatile("" : "+v"(a));
+    asm volatile("" : "+v"(b));
+    p.g1c = a; p.g2c = b;
+    const double e1 = fabs(__builtin_fma(fn.xmin, p.g1w, p.g1c)), e2 = fabs(__builtin_fma(fn.xmax, p.g1w, p.g1c));
+    const double e3 = fabs(__builtin_fma(fn.xmin, p.g2w, p.g2c)), e4 = fabs(__builtin_fma(fn.xmax, p.g2w, p.g2c));
+    p.fast = (e1 < 46000.0) && (e2 < 46000.0) && (e3 < 46000.0) && (e4 < 46000.0);  // NaN fails
+    p.K.pin();
     return p;
   }
+  static __device__ __forceinline__ bool fast_ok(const Prep& p) { return p.fast; }
+  template <bool FAST>
   static __device__ __forceinline__ double eval(const Prep& p, double x) {
     const double u1 = __builtin_fma(x, p.iw1, p.c1), u2 = __builtin_fma(x, p.iw2, p.c2p);
-    const double g1 = mexp2_negsq_safe(u1 * kSqrtLog2e), g2 = mexp2_negsq_safe(u2 * kSqrtLog2e);
+    double g1, g2;
+    if (FAST) {
+      g1 = mexp2_negsq(__builtin_fma(x, p.g1w, p.g1c), p.K);
+      g2 = mexp2_negsq(__builtin_fma(x, p.g2w, p.g2c), p.K);
+    } else {
+      g1 = mexp2_negsq_safe(u1 * kSqrtLog2e);
+      g2 = mexp2_negsq_safe(u2 * kSqrtLog2e);
+    }
     const double l1 = frcp(__builtin_fma(u1, u1, 1.0)), l2 = frcp(__builtin_fma(u2, u2, 1.0));
     const double pv1 = __builtin_fma(p.eta1, l1, p.om1 * g1);
     const double pv2 = __builtin_fma(p.eta2, l2, p.om2 * g2);
