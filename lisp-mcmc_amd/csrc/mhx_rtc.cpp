@@ -373,19 +373,29 @@ int rtc_build(const std::vector<UserExpr>& models, const std::vector<UserExpr>& 
 std::shared_ptr<UserProgram> rtc_get(const std::vector<UserExpr>& models,
                                      const std::vector<UserExpr>& priors, bool builtin_fallback,
                                      const Family& fam, std::string* err) {
-  static std::mutex mu;
-  static std::map<std::string, std::weak_ptr<UserProgram>> cache;
+  // The newest kCap modules stay loaded for the life of the process (an engine that is created
+  // again for the same problem - a loop over datasets, a test suite - does not compile again).
+  // The containers are leaked on purpose: unloading modules from a static destructor would race
+  // the HIP runtime's own shutdown.
+  constexpr size_t kCap = 48;
+  static std::mutex& mu = *new std::mutex;
+  static auto& cache = *new std::map<std::string, std::shared_ptr<UserProgram>>;
+  static auto& order = *new std::vector<std::string>;
   int dev = 0;
   (void)hipGetDevice(&dev);
   const std::string key = "dev" + std::to_string(dev) + "|" +
                           generate(models, priors, builtin_fallback, 4, fam.threads);
   std::lock_guard<std::mutex> lock(mu);
   auto it = cache.find(key);
-  if (it != cache.end())
-    if (std::shared_ptr<UserProgram> hit = it->second.lock()) return hit;
+  if (it != cache.end()) return it->second;
   std::shared_ptr<UserProgram> prog(new UserProgram());
   if (rtc_build(models, priors, builtin_fallback, fam, prog.get(), err) != 0) return nullptr;
+  if (order.size() >= kCap) {  // engines still using the oldest one keep it alive themselves
+    cache.erase(order.front());
+    order.erase(order.begin());
+  }
   cache[key] = prog;
+  order.push_back(key);
   return prog;
 }
 
