@@ -115,7 +115,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # 200 = up to and including the first proposal-adaptation tick of the walk (M:929): the first
+    # 200 of a run's 30000 iterations (annealing at T = 10 with the untuned initial L matrix)
+    # propose wide, often out-of-bounds steps and run ~12 % slower than everything after them
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)

@@ -6,7 +6,7 @@ TAG=${1:-r01}; shift || true
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf $R && mkdir -p $R
-ARGS="--no-cpu --steps 200 --warmup 20 $*"
+ARGS="--no-cpu $*"   # bench.py defaults: 200 warm-up + 200 timed iterations, one launch each
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/stats -- python3 /root/repo/bench.py $ARGS > $R/bench_stats.json 2> $R/stats.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/fetch -- python3 /root/repo/bench.py $ARGS > /dev/null 2> $R/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/write -- python3 /root/repo/bench.py $ARGS > /dev/null 2> $R/write.err
