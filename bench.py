@@ -184,6 +184,12 @@ def main():
     # comparable with the HIP-event average reported below.
     import math
     per_launch = math.gcd(args.steps, args.warmup) if args.warmup > 0 else args.steps
+    # ... and no launch much longer than a second (config 3 at its full 65536 chains x 1e6 points
+    # takes 0.14 s per iteration): the largest divisor that keeps chains x points x iterations
+    # under 1e12
+    work = chains * float(sum(len(d[0]) for d in spec.data))
+    while per_launch > 1 and work * per_launch > 1e12:
+        per_launch = max(q for q in range(1, per_launch) if per_launch % q == 0)
     for _ in range(args.warmup // per_launch if args.warmup > 0 else 0):
         e.adaptive_advance(per_launch, count=False)
     e.kernel_timing(reset=True)
