@@ -116,3 +116,65 @@ def test_mixed_problem_every_function_specialised(mhx, orc):
     for i in range(len(t)):
         assert abs(got[i] - op.logpost(t[i])) <= REL * op.abs_terms(t[i])
     e.close()
+
+
+def random_peaks_problem(rng, model, nbg, npk, lik, n):
+    th = []
+    for j in range(nbg):
+        th.append([0.6, 0.25, -0.15, 0.08][j] * rng.uniform(0.8, 1.2))
+    for k in range(npk):
+        th += [rng.uniform(0.4, 1.5), (k + rng.uniform(0.3, 0.7)) / npk, rng.uniform(0.02, 0.2)]
+    th = np.array(th if th else [0.0])
+    x = np.sort(rng.uniform(0.0, 1.0, n))
+    f = pb.model_eval_np(model, (nbg, npk), th, x)
+    d = len(th)
+    s = pb.Spec(d)
+    lo, hi = np.minimum(th * 0.5, th * 1.5) - 1e-9, np.maximum(th * 0.5, th * 1.5) + 1e-9
+    if lik == pb.POISSON:
+        scale = 60.0 / max(f.max(), 1e-9)
+        th = th.copy()
+        idx = list(range(nbg)) + [nbg + 3 * k for k in range(npk)]
+        th[idx] *= scale
+        lam = pb.model_eval_np(model, (nbg, npk), th, x)
+        lam = np.where(lam > 0.5, lam, 0.5)
+        s.add(model, (nbg, npk), range(d), x, rng.poisson(lam).astype(float), None, lik,
+              (list(range(d)), np.minimum(th * 0.5, th * 1.5) - 1e-9, np.maximum(th * 0.5, th * 1.5) + 1e-9))
+    else:
+        sig = rng.uniform(0.05, 0.2, n)
+        s.add(model, (nbg, npk), range(d), x, f + sig * rng.standard_normal(n), sig, lik,
+              (list(range(d)), lo, hi))
+    s.theta_star = th
+    return s
+
+
+def test_random_shapes_against_the_oracle(mhx, orc):
+    """every (background terms, peaks, line shape, likelihood) the run-time specialiser accepts,
+    sampled at random: each is its own template instantiation"""
+    rng = np.random.default_rng(2024)
+    seen = set()
+    for trial in range(14):
+        model = pb.GAUSS if rng.random() < 0.6 else pb.LORENTZ
+        nbg, npk = int(rng.integers(0, 5)), int(rng.integers(1, 7))
+        lik = [pb.NORMAL, pb.CUTOFF, pb.POISSON][int(rng.integers(0, 3))]
+        if lik == pb.POISSON and nbg == 0:
+            nbg = 1  # a Poisson rate needs a positive floor between the peaks
+        if (model, nbg, npk, lik) in seen or nbg + 3 * npk > 32:
+            continue
+        seen.add((model, nbg, npk, lik))
+        n = int(rng.choice([700, 1024, 2500, 5000]))
+        s = random_peaks_problem(rng, model, nbg, npk, lik, n)
+        e = s.engine(mhx, 2)
+        name = e.kernel_name()
+        want = "rtc[PeaksModel<%d, %d, %s>" % (nbg, npk, "true" if model == pb.LORENTZ else "false")
+        assert want in name or ("rtc" not in name and "generic" not in name), name  # or ahead-of-time
+        op = s.oracle(orc)
+        th = pb.perturbed(s.theta_star, 10, 0.02, seed=trial)
+        got, parts = e.logpost(th, parts=True)
+        for i in range(len(th)):
+            ref, rp = op.logpost(th[i], parts=True)
+            if not np.isfinite(ref):
+                assert not np.isfinite(got[i]) or abs(got[i]) > 1e9, (name, i)
+                continue
+            assert abs(parts[i, 0] - rp[0]) <= REL * op.abs_terms(th[i]), (name, i, parts[i, 0], rp[0])
+        e.close()
+    assert len(seen) >= 8
