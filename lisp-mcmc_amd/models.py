@@ -17,12 +17,29 @@ class Model:
         self.shape = tuple(int(s) for s in shape)
         self.expr = expr  # C-syntax body for MODEL_EXPR
 
+    def __repr__(self):
+        return "Model(%d, %r, %r)" % (self.model_id, self.keys, self.shape)
 
-def lisp(lambda_text):
+
+def lisp(lambda_text, recognise=True):
     """An arbitrary model from the TEXT of the reference-style closure, e.g.
     lisp('(lambda (x &key m b &allow-other-keys) (+ b (* m x)))').  The body is translated to a
-    C expression (sexpr.py) and compiled for gfx950 at walker-create time (hiprtc)."""
+    C expression (sexpr.py) and compiled for gfx950 at walker-create time (hiprtc).
+
+    recognise: a body that IS a polynomial background plus Gaussian (or Lorentzian) peaks of the
+    form a*exp(-((x-mu)/w)^2) (a/(1+((x-mu)/w)^2)) is handed to the engine as that enumerated
+    model instead - same function, evaluated with the peak kernels' fused arithmetic (a few ulp
+    from the closure's own rounding, well inside the parity tolerance) and their tile-level
+    skipping.  recognise=False always compiles the expression as written."""
     from . import sexpr
+    if recognise:
+        hit = sexpr.recognise_peaks(lambda_text)
+        if hit is not None:
+            model_id, shape, keys = hit
+            m = Model(model_id, keys, shape)
+            # (an expression likelihood needs an expression model: walker_create falls back)
+            m.source_expr = sexpr.lambda_to_expr(lambda_text)
+            return m
     keys, expr = sexpr.lambda_to_expr(lambda_text)
     return Model(capi.MODEL_EXPR, keys, expr=expr)
 
@@ -31,9 +48,6 @@ def expr(c_expression, keys):
     """An arbitrary model from a C-syntax expression over x and the keys (include/mhx.h)."""
     from . import sexpr
     return Model(capi.MODEL_EXPR, [sexpr.mangle(k) for k in keys], expr=c_expression)
-
-    def __repr__(self):
-        return "Model(%d, %r, %r)" % (self.model_id, self.keys, self.shape)
 
 
 def poly(*keys):

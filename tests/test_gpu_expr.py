@@ -254,3 +254,25 @@ def test_custom_likelihood_errors(mhx):
                           data=[x, y], params=[":b", 0, ":m", 1],
                           log_liklihood=mhx.create_log_liklihood_function(
                               "(lambda (y model error) (* scale (- y model)))"))
+
+
+def test_recognised_peak_closure_runs_on_the_peak_kernels(mhx, orc):
+    """models.lisp() recognises background + Gaussian peaks and hands the enumerated model over:
+    same kernel, same bits as models.gauss_peaks(); the closure compiled as written agrees within
+    the stated tolerance"""
+    s = pb.two_peak(n=5000, seed=91)
+    x, y, sig, _ = s.data[0]
+    params = [":b0", 0.5, ":b1", 0.3, ":a1", 1.0, ":mu1", 0.3, ":w1", 0.05, ":a2", 0.7, ":mu2", 0.7, ":w2", 0.08]
+    ws = [mhx.walker_create(function=f, data=[x, y], params=params, data_error=sig, n_chains=3, seed=5)
+          for f in (mhx.models.lisp(TWO_PEAK),
+                    mhx.models.gauss_peaks(["b0", "b1"], [("a1", "mu1", "w1"), ("a2", "mu2", "w2")]),
+                    mhx.models.lisp(TWO_PEAK, recognise=False))]
+    names = [w.engine.kernel_name() for w in ws]
+    assert names[0] == names[1] and "gauss22_normal" in names[0] and "rtc[expr" in names[2]
+    p = [w.last_step().prob for w in ws]
+    assert p[0] == p[1]
+    op = s.oracle(orc)
+    assert abs(p[2] - p[0]) <= 2 * REL * op.abs_terms(s.theta_star)
+    for w in ws[:2]:
+        mhx.walker_adaptive_steps(w, 1200)
+    assert np.array_equal(ws[0].engine.state()["theta"], ws[1].engine.state()["theta"])

@@ -135,3 +135,32 @@ def test_rejects_unsupported_forms(sx):
         sx.lambda_to_expr("(defun f (x) x)")
     assert sx.number("1d-5") == "1e-5" and sx.number("2") == "2.0" and sx.number("1/2") == "(1.0/2.0)"
     assert sx.mangle(":much-better-param-name1") == "much_better_param_name1"
+
+
+def test_peak_closures_are_recognised(sx):
+    """models.lisp() hands closures that ARE background + Gaussian / Lorentzian peaks to the
+    engine as the enumerated model (sexpr.recognise_peaks)"""
+    R = sx.recognise_peaks
+    assert R("(lambda (x &key b0 b1 a1 mu1 w1 a2 mu2 w2 &allow-other-keys) (+ (+ b0 (* b1 x))"
+             " (* a1 (exp (- (expt (/ (- x mu1) w1) 2)))) (* a2 (exp (- (expt (/ (- x mu2) w2) 2))))))") == \
+        (1, (2, 2), ["b0", "b1", "a1", "mu1", "w1", "a2", "mu2", "w2"])
+    assert R("(lambda (x &key bg a mu w &allow-other-keys) (+ bg (* (exp (* -1 (expt (/ (- x mu) w) 2d0))) a)))") == \
+        (1, (1, 1), ["bg", "a", "mu", "w"])
+    assert R("(lambda (x &key a x0 g c m q &allow-other-keys) (+ (* q (expt x 2)) c (* m x)"
+             " (* a (/ 1 (1+ (* (/ (- x x0) g) (/ (- x x0) g)))))))") == (2, (3, 1), ["c", "m", "q", "a", "x0", "g"])
+    assert R("(lambda (x &key a x0 g &allow-other-keys) (/ a (+ (expt (/ (- x x0) g) 2) 1)))") == \
+        (2, (0, 1), ["a", "x0", "g"])
+    for text in (
+            "(lambda (x &key m b &allow-other-keys) (+ b (* m x)))",                                  # no peak
+            "(lambda (x &key a mu w &allow-other-keys) (* 2 a (exp (- (expt (/ (- x mu) w) 2)))))",   # extra factor
+            "(lambda (x &key a mu &allow-other-keys) (* a (exp (- (expt (/ (- x mu) a) 2)))))",       # a key used twice
+            "(lambda (x &key a mu w &allow-other-keys) (* a (exp (- (expt (/ (- x mu) w) 4)))))",     # not a Gaussian
+            "(lambda (x &key a mu w c &allow-other-keys) (+ (* c (expt x 2)) (* a (exp (- (expt (/ (- x mu) w) 2))))))",  # gap in bg
+            "(lambda (x &key a mu w (c 1d0) &allow-other-keys) (+ c (* a (exp (- (expt (/ (- x mu) w) 2))))))",           # defaults
+            "(lambda (x &key a mu w b g &allow-other-keys) (+ (* a (exp (- (expt (/ (- x mu) w) 2)))) (/ b (+ 1 (expt (/ (- x mu) g) 2)))))"):
+        assert R(text) is None, text
+    import lisp_mcmc_amd
+    m = lisp_mcmc_amd.models.lisp("(lambda (x &key bg a mu w &allow-other-keys) (+ bg (* a (exp (- (expt (/ (- x mu) w) 2))))))")
+    assert (m.model_id, m.shape, m.keys) == (1, (1, 1), ["bg", "a", "mu", "w"]) and m.source_expr[0] == ["bg", "a", "mu", "w"]
+    m = lisp_mcmc_amd.models.lisp("(lambda (x &key bg a mu w &allow-other-keys) (+ bg (* a (exp (- (expt (/ (- x mu) w) 2))))))", recognise=False)
+    assert m.model_id == lisp_mcmc_amd.capi.MODEL_EXPR
