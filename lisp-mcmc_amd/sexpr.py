@@ -235,7 +235,8 @@ def recognise_peaks(text):
                   (/ a (+ 1 (expt (/ (- x mu) w) 2)))                Lorentzian
        (a, mu, w, c_i bare keys, each used once; (1+ ..), (* u u), (* -1 ..), either order of the
        factors are understood), return (model id, (nbg, npk), keys in the enumerated model's
-       order); otherwise None.  MODEL ids as in include/mhx.h: 1 Gaussian, 2 Lorentzian peaks."""
+       order); a body that is only the polynomial gives (0, (), keys by degree); otherwise None.
+       MODEL ids as in include/mhx.h: 0 polynomial, 1 Gaussian, 2 Lorentzian peaks."""
     try:
         form = parse(text)
         if isinstance(form, list) and len(form) == 2 and form[0] in ("function", "quote"):
@@ -360,10 +361,14 @@ def recognise_peaks(text):
             return None
         bg[deg] = key
     peaks = gauss or lorentz
-    if not peaks or (gauss and lorentz) or len(peaks) > 6:
-        return None
     nbg = len(bg)
-    if sorted(bg) != list(range(nbg)) or nbg > 4:
+    if sorted(bg) != list(range(nbg)):
+        return None
+    if not peaks:  # a plain polynomial c0 + c1 x + ...: MODEL_POLY (id 0), keys by degree
+        if nbg < 1 or nbg > 16 or len(set(bg.values())) != nbg:
+            return None
+        return 0, (), [mangle(bg[i]) for i in range(nbg)]
+    if (gauss and lorentz) or len(peaks) > 6 or nbg > 4:
         return None
     used = [bg[i] for i in range(nbg)] + [k for p in peaks for k in p]
     if len(set(used)) != len(used):

@@ -151,7 +151,6 @@ def test_peak_closures_are_recognised(sx):
     assert R("(lambda (x &key a x0 g &allow-other-keys) (/ a (+ (expt (/ (- x x0) g) 2) 1)))") == \
         (2, (0, 1), ["a", "x0", "g"])
     for text in (
-            "(lambda (x &key m b &allow-other-keys) (+ b (* m x)))",                                  # no peak
             "(lambda (x &key a mu w &allow-other-keys) (* 2 a (exp (- (expt (/ (- x mu) w) 2)))))",   # extra factor
             "(lambda (x &key a mu &allow-other-keys) (* a (exp (- (expt (/ (- x mu) a) 2)))))",       # a key used twice
             "(lambda (x &key a mu w &allow-other-keys) (* a (exp (- (expt (/ (- x mu) w) 4)))))",     # not a Gaussian
@@ -159,6 +158,9 @@ def test_peak_closures_are_recognised(sx):
             "(lambda (x &key a mu w (c 1d0) &allow-other-keys) (+ c (* a (exp (- (expt (/ (- x mu) w) 2))))))",           # defaults
             "(lambda (x &key a mu w b g &allow-other-keys) (+ (* a (exp (- (expt (/ (- x mu) w) 2)))) (/ b (+ 1 (expt (/ (- x mu) g) 2)))))"):
         assert R(text) is None, text
+    assert R("(lambda (x &key m b &allow-other-keys) (+ b (* m x)))") == (0, (), ["b", "m"])
+    assert R("(lambda (x &key b m c d &allow-other-keys) (+ b (* m x) (* c x x) (* d x x x)))") == (0, (), ["b", "m", "c", "d"])
+    assert R("(lambda (x &key m b &allow-other-keys) (+ b (* -3 m) (* m x)))") is None
     import lisp_mcmc_amd
     m = lisp_mcmc_amd.models.lisp("(lambda (x &key bg a mu w &allow-other-keys) (+ bg (* a (exp (- (expt (/ (- x mu) w) 2))))))")
     assert (m.model_id, m.shape, m.keys) == (1, (1, 1), ["bg", "a", "mu", "w"]) and m.source_expr[0] == ["bg", "a", "mu", "w"]
