@@ -11,6 +11,8 @@
 #include <mutex>
 #include <set>
 #include <sstream>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "mhx_launch.hpp"
 
@@ -32,6 +34,7 @@ struct Hiprtc {
   int (*GetCode)(hiprtcProgram, char*);
   int (*DestroyProgram)(hiprtcProgram*);
   const char* (*GetErrorString)(int);
+  int (*Version)(int*, int*);
   bool ok = false;
 };
 Hiprtc& rtc() {
@@ -52,6 +55,7 @@ Hiprtc& rtc() {
   SYM(GetCode, "hiprtcGetCode");
   SYM(DestroyProgram, "hiprtcDestroyProgram");
   SYM(GetErrorString, "hiprtcGetErrorString");
+  SYM(Version, "hiprtcVersion");
 #undef SYM
   r.ok = r.CreateProgram && r.CompileProgram && r.GetProgramLogSize && r.GetProgramLog &&
          r.GetCodeSize && r.GetCode && r.DestroyProgram;
@@ -275,6 +279,79 @@ static std::string generate(const std::vector<UserExpr>& models,
   return s.str();
 }
 
+// ---- on-disk cache of compiled code objects ---------------------------------------------------
+// A compile costs 1-2 s; the same problem in the next process should not pay it again.  Files live
+// in $MHX_RTC_CACHE_DIR, else $XDG_CACHE_HOME/mhx, else ~/.cache/mhx (MHX_RTC_CACHE_DIR=off
+// disables); a file is trusted only if the full key stored inside it - hiprtc version, build
+// options, embedded headers, generated source - equals the one being asked for.
+static uint64_t fnv1a(const std::string& s, uint64_t h) {
+  for (unsigned char c : s) {
+    h ^= c;
+    h *= 1099511628211ULL;
+  }
+  return h;
+}
+static std::string cache_dir() {
+  const char* d = getenv("MHX_RTC_CACHE_DIR");
+  if (d && (!strcmp(d, "off") || !strcmp(d, "0") || !*d)) return "";
+  std::string dir;
+  if (d) {
+    dir = d;
+  } else if (const char* x = getenv("XDG_CACHE_HOME")) {
+    dir = std::string(x) + "/mhx";
+  } else if (const char* h = getenv("HOME")) {
+    dir = std::string(h) + "/.cache";
+    (void)mkdir(dir.c_str(), 0700);
+    dir += "/mhx";
+  } else {
+    return "";
+  }
+  (void)mkdir(dir.c_str(), 0700);
+  return dir;
+}
+static std::string cache_path(const std::string& key) {
+  const std::string dir = cache_dir();
+  if (dir.empty()) return "";
+  char name[64];
+  snprintf(name, sizeof name, "/%016llx%016llx.co",
+           (unsigned long long)fnv1a(key, 14695981039346656037ULL),
+           (unsigned long long)fnv1a(key, 0x9E3779B97F4A7C15ULL));
+  return dir + name;
+}
+static bool cache_load(const std::string& key, std::vector<char>* code) {
+  const std::string path = cache_path(key);
+  if (path.empty()) return false;
+  FILE* fp = fopen(path.c_str(), "rb");
+  if (!fp) return false;
+  bool ok = false;
+  char magic[6] = {0};
+  uint64_t kl = 0, cl = 0;
+  if (fread(magic, 1, 6, fp) == 6 && !memcmp(magic, "MHXC1\n", 6) && fread(&kl, 8, 1, fp) == 1 &&
+      kl == key.size()) {
+    std::string k(kl, '\0');
+    if (fread(&k[0], 1, kl, fp) == kl && k == key && fread(&cl, 8, 1, fp) == 1 && cl > 0 &&
+        cl < (1ull << 30)) {
+      code->resize(cl);
+      ok = fread(code->data(), 1, cl, fp) == cl;
+    }
+  }
+  fclose(fp);
+  return ok;
+}
+static void cache_store(const std::string& key, const std::vector<char>& code) {
+  const std::string path = cache_path(key);
+  if (path.empty()) return;
+  const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+  FILE* fp = fopen(tmp.c_str(), "wb");
+  if (!fp) return;
+  const uint64_t kl = key.size(), cl = code.size();
+  const bool ok = fwrite("MHXC1\n", 1, 6, fp) == 6 && fwrite(&kl, 8, 1, fp) == 1 &&
+                  fwrite(key.data(), 1, kl, fp) == kl && fwrite(&cl, 8, 1, fp) == 1 &&
+                  fwrite(code.data(), 1, cl, fp) == cl;
+  fclose(fp);
+  if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
+}
+
 static int build_once(const std::vector<UserExpr>& models, const std::vector<UserExpr>& priors,
                       bool builtin_fallback, const Family& fam, int min_waves, UserProgram* prog,
                       std::string* err) {
@@ -294,42 +371,66 @@ static int build_once(const std::vector<UserExpr>& models, const std::vector<Use
                            kSrc_mhx_h};
   const char* hdr_name[] = {"mhx_kernels.hpp", "mhx_device.hpp", "mhx_types.hpp",
                             "../../include/mhx.h"};
-  hiprtcProgram p = nullptr;
-  int rc = r.CreateProgram(&p, prog->source.c_str(), "mhx_user.hip", 4, hdr_src, hdr_name);
-  if (rc != 0) {
-    *err = std::string("hiprtcCreateProgram: ") + (r.GetErrorString ? r.GetErrorString(rc) : "?");
-    return -1;
-  }
   // the same family defines the ahead-of-time build of this workgroup shape gets (Makefile)
   const std::string wpg = "-DMHX_WPG=" + std::to_string(fam.waves_per_group);
   const std::string famns = "-DMHX_FAMILY=w" + std::to_string(fam.waves_per_group);
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                         wpg.c_str(), famns.c_str()};
-  rc = r.CompileProgram(p, 6, opts);
-  size_t ls = 0;
-  if (r.GetProgramLogSize(p, &ls) == 0 && ls > 1) {
-    prog->log.resize(ls);
-    r.GetProgramLog(p, &prog->log[0]);
+  int vmaj = 0, vmin = 0;
+  if (r.Version) (void)r.Version(&vmaj, &vmin);
+  std::string key = "mhx-rtc-1|hiprtc " + std::to_string(vmaj) + "." + std::to_string(vmin) + "|";
+  for (const char* o : opts) key += std::string(o) + " ";
+  for (const char* h : hdr_src)
+    key += "|" + std::to_string((unsigned long long)fnv1a(h, 14695981039346656037ULL));
+  key += "|" + prog->source;
+  std::vector<char> code;
+  bool from_cache = cache_load(key, &code);
+  if (from_cache) {  // a file that does not load (truncated, other driver) is dropped and rebuilt
+    if (prog->module) {
+      (void)hipModuleUnload(prog->module);
+      prog->module = nullptr;
+    }
+    if (hipModuleLoadData(&prog->module, code.data()) != hipSuccess) {
+      prog->module = nullptr;
+      (void)remove(cache_path(key).c_str());
+      from_cache = false;
+    }
   }
-  if (rc != 0) {
-    *err = "hiprtc compilation of the expression failed:\n" + prog->log.substr(0, 3000);
+  if (!from_cache) {
+    hiprtcProgram p = nullptr;
+    int rc = r.CreateProgram(&p, prog->source.c_str(), "mhx_user.hip", 4, hdr_src, hdr_name);
+    if (rc != 0) {
+      *err = std::string("hiprtcCreateProgram: ") + (r.GetErrorString ? r.GetErrorString(rc) : "?");
+      return -1;
+    }
+    rc = r.CompileProgram(p, 6, opts);
+    size_t ls = 0;
+    if (r.GetProgramLogSize(p, &ls) == 0 && ls > 1) {
+      prog->log.resize(ls);
+      r.GetProgramLog(p, &prog->log[0]);
+    }
+    if (rc != 0) {
+      *err = "hiprtc compilation of the expression failed:\n" + prog->log.substr(0, 3000);
+      r.DestroyProgram(&p);
+      return -1;
+    }
+    size_t cs = 0;
+    r.GetCodeSize(p, &cs);
+    code.resize(cs);
+    r.GetCode(p, code.data());
     r.DestroyProgram(&p);
-    return -1;
+    if (prog->module) {
+      (void)hipModuleUnload(prog->module);
+      prog->module = nullptr;
+    }
+    const hipError_t le = hipModuleLoadData(&prog->module, code.data());
+    if (le != hipSuccess) {
+      *err = std::string("hipModuleLoadData: ") + hipGetErrorString(le);
+      return -1;
+    }
+    cache_store(key, code);
   }
-  size_t cs = 0;
-  r.GetCodeSize(p, &cs);
-  std::vector<char> code(cs);
-  r.GetCode(p, code.data());
-  r.DestroyProgram(&p);
-  if (prog->module) {
-    (void)hipModuleUnload(prog->module);
-    prog->module = nullptr;
-  }
-  hipError_t he = hipModuleLoadData(&prog->module, code.data());
-  if (he != hipSuccess) {
-    *err = std::string("hipModuleLoadData: ") + hipGetErrorString(he);
-    return -1;
-  }
+  hipError_t he = hipSuccess;
   struct { hipFunction_t* f; const char* n; } fs[] = {{&prog->f_logpost, "mhx_user_logpost"},
                                                       {&prog->f_init, "mhx_user_init"},
                                                       {&prog->f_step, "mhx_user_step"},

@@ -178,3 +178,45 @@ def test_random_shapes_against_the_oracle(mhx, orc):
             assert abs(parts[i, 0] - rp[0]) <= REL * op.abs_terms(th[i]), (name, i, parts[i, 0], rp[0])
         e.close()
     assert len(seen) >= 8
+
+
+CACHE_SCRIPT = r"""
+import sys, time
+sys.path.insert(0, %r)
+import numpy as np
+import lisp_mcmc_amd as mhx
+rng = np.random.default_rng(77)
+x = np.linspace(0, 1, 400)
+y = 0.3 + np.exp(-((x - 0.47) / 0.09) ** 2) + 0.05 * rng.standard_normal(400)
+text = "(lambda (x &key c a m s &allow-other-keys) (+ c (* 1.0000077 a (exp (- (expt (/ (- x m) s) 2))))))"
+t0 = time.perf_counter()
+w = mhx.walker_create(function=mhx.models.lisp(text), data=[x, y],
+                      params=[":c", 0.3, ":a", 1.0, ":m", 0.47, ":s", 0.09], data_error=0.05)
+print("RESULT %%.6f %%r %%s" %% (time.perf_counter() - t0, w.last_step().prob, w.engine.kernel_name()))
+"""
+
+
+def test_compiled_kernels_are_cached_on_disk(tmp_path):
+    """a second PROCESS asking for the same problem loads the code object instead of compiling
+    (MHX_RTC_CACHE_DIR); an entry that does not load is rebuilt, not trusted"""
+    import glob
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MHX_RTC_CACHE_DIR=str(tmp_path))
+
+    def run():
+        out = subprocess.check_output([sys.executable, "-c", CACHE_SCRIPT % root], env=env).decode()
+        line = [ln for ln in out.splitlines() if ln.startswith("RESULT")][0].split(" ", 3)
+        return float(line[1]), line[2], line[3]
+    t1, p1, k1 = run()
+    files = glob.glob(str(tmp_path / "*.co"))
+    assert len(files) == 1 and os.path.getsize(files[0]) > 10000 and "rtc[expr" in k1
+    assert open(files[0], "rb").read(6) == b"MHXC1\n"
+    t2, p2, k2 = run()
+    assert p2 == p1 and k2 == k1 and len(glob.glob(str(tmp_path / "*.co"))) == 1
+    assert t2 < 0.6 * t1, (t1, t2)        # loading beats compiling
+    blob = open(files[0], "rb").read()
+    open(files[0], "wb").write(blob[: len(blob) // 2])   # truncated: must be rebuilt
+    t3, p3, _ = run()
+    assert p3 == p1 and os.path.getsize(files[0]) == len(blob)
