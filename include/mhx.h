@@ -18,7 +18,10 @@
  *   walker-adaptive-steps      M:946-947     -> mhx_adaptive_steps
  *   walker-many-steps          M:849-853     -> mhx_many_steps
  *   walker-get                 M:487-543     -> mhx_get_state / _acceptance / _lmatrix /
- *                                               _trace / _forward_count
+ *                                               _trace / _proposal_factor
+ *   walker-modify              M:547-580     -> mhx_walker_modify (+ mhx_set_history)
+ *   create-log-liklihood-function M:402-416  -> mhx_set_likelihood_expr
+ *   prior-bounds-let           M:346-369     -> mhx_set_bounds (+ mhx_set_prior_expr)
  *   mfit-walker-estop          M:860-861     -> mhx_request_stop
  *
  * Conventions: every function returns MHX_OK (0) or a negative MHX_E* code and never
