@@ -116,6 +116,11 @@ struct mhx_engine {
   DevBuf<uint64_t> draw;
   DevBuf<int32_t> shutting, status, fwd_idx, stop_flag;
   DevBuf<unsigned long long> step_counter;
+  // split mode (few chains, long datasets): 0 = batch kernels, else workgroups per chain
+  int split_slices = 0;
+  int64_t split_portion = 512;  // iterations queued between two looks at the chain states
+  DevBuf<double> split_prop, split_u, split_part;
+  DevBuf<int32_t> split_pending;
   bool chains_ready = false;
 
   RunDesc R{};
@@ -160,6 +165,32 @@ std::string builtin_model_type(const FnDesc& f) {
     case MHX_MODEL_PVOIGT2: return "PVoigt2Model";
     default: return "";
   }
+}
+
+// Split mode (mhx_kernels.hpp): how many workgroups share one chain's likelihood sums, or 0 for
+// the batch kernels.  Worth it when the batch launch would leave most CUs without a workgroup
+// and every (slice, wave) slot still gets at least 512 points of the longest dataset.
+// MHX_SPLIT=0 switches it off, MHX_SPLIT=<n> forces n slices.
+int choose_split(const mhx_engine* e, const Family& fam, bool capable) {
+  if (!capable || e->cfg.adapt_mode == MHX_ADAPT_POOLED) return 0;
+  int64_t longest = 0;
+  for (int k = 0; k < e->P.K; ++k) longest = std::max<int64_t>(longest, e->P.fn[k].n);
+  const int64_t C = e->cfg.n_chains;
+  const int W = fam.waves_per_group;
+  const int64_t by_data = longest / (512 * (int64_t)W);
+  if (const char* s = getenv("MHX_SPLIT")) {
+    const int v = atoi(s);
+    return v <= 0 ? 0 : (int)std::min<int64_t>(std::max<int64_t>(by_data, 1), v);
+  }
+  // measured on config 2's problem (tools/ab notes in DESIGN.md): the batch kernels win once they
+  // put a workgroup on every CU (2048 chains: 9.0e6 against 5.9e6 chain-steps/s); below that,
+  // about 1024 workgroups in the sweep launch are best (1024 chains x2: 5.6e6 against 4.6e6,
+  // 256 chains x4: 4.4e6 against 1.2e6, one chain x24: 6.0e4 against 7.5e3)
+  const int64_t batch_groups = (C + W - 1) / W;
+  if (batch_groups >= 256) return 0;
+  const int64_t slices = std::min<int64_t>(std::max<int64_t>(2, std::min<int64_t>(1024 / C, 24)),
+                                           by_data);
+  return slices >= 2 ? (int)slices : 0;
 }
 
 // Which workgroup shape serves this problem (mhx_types.hpp).  16 chains per workgroup and
@@ -281,7 +312,9 @@ int finalize_problem(mhx_engine* e) {
     }
     HIP_TRY(hipMemcpy(e->dP.p, &e->P, sizeof(ProblemDesc), hipMemcpyHostToDevice));
     std::string err;
-    std::shared_ptr<UserProgram> prog = rtc_get(models, priors, builtin, *e->fam, &err);
+    const bool want_split = choose_split(e, *e->fam, !builtin) > 0;
+    std::shared_ptr<UserProgram> prog =
+        rtc_get(models, priors, builtin, want_split, *e->fam, &err);
     if (prog) {
       e->user_prog = prog;
       e->spec = SPEC_USER;
@@ -294,6 +327,21 @@ int finalize_problem(mhx_engine* e) {
       e->user_prog.reset();
       e->spec = SPEC_GENERIC;
     }
+  }
+  // split mode for small batches on long datasets
+  {
+    const bool capable = e->spec == SPEC_USER ? e->user_prog->has_split
+                                              : e->fam->split_capable(e->spec);
+    e->split_slices = choose_split(e, *e->fam, capable);
+    e->S.split_slots = e->split_slices * e->fam->waves_per_group;
+    e->S.split_part = nullptr;
+    if (e->split_slices > 0) {
+      const size_t np = (size_t)e->cfg.n_chains * e->P.K * e->S.split_slots;
+      if (e->split_part.alloc(np) != hipSuccess)
+        return fail(MHX_ENOMEM, "hipMalloc of the split-mode partial sums failed");
+      e->S.split_part = e->split_part.p;
+    }
+    HIP_TRY(hipMemset(e->split_pending.p, 0, (size_t)e->cfg.n_chains * sizeof(int32_t)));
   }
   // a name for what was chosen (mhx_kernel_name)
   static const char* kLik[] = {"normal", "normal_cutoff", "poisson", "expr"};
@@ -311,6 +359,7 @@ int finalize_problem(mhx_engine* e) {
     e->kernel_name += spec_name(e->spec);
     if (!e->rtc_note.empty()) e->kernel_name += " [not specialised: " + e->rtc_note + "]";
   }
+  if (e->split_slices > 0) e->kernel_name += " split x" + std::to_string(e->split_slices);
   e->problem_dirty = false;
   return MHX_OK;
 }
@@ -330,6 +379,16 @@ hipError_t do_step_injected(mhx_engine* e, const double* L, int pcl, const doubl
   return e->spec == SPEC_USER
              ? rtc_launch_step_injected(*e->user_prog, e->stream, e->dP.p, e->S, L, pcl, z, u, T, acc)
              : e->fam->step_injected(e->spec, e->stream, e->dP.p, e->S, L, pcl, z, u, T, acc);
+}
+hipError_t do_split_sweep(mhx_engine* e) {
+  return e->spec == SPEC_USER
+             ? rtc_launch_split_sweep(*e->user_prog, e->stream, e->dP.p, e->S, e->split_slices)
+             : e->fam->split_sweep(e->spec, e->stream, e->dP.p, e->S, e->split_slices);
+}
+hipError_t do_split_step(mhx_engine* e, int mode, int plain) {
+  return e->spec == SPEC_USER
+             ? rtc_launch_split_step(*e->user_prog, e->stream, e->dP.p, e->S, e->R, mode, plain)
+             : e->fam->split_step(e->spec, e->stream, e->dP.p, e->S, e->R, mode, plain);
 }
 hipError_t do_adaptive(mhx_engine* e, int64_t iters, int plain) {
   return e->spec == SPEC_USER
@@ -416,6 +475,9 @@ int alloc_state(mhx_engine* e) {
   ALLOC(pool_vec, 1 + d + d * d);
   ALLOC(L_pool, d * d);
   ALLOC(pool_valid, 1);
+  ALLOC(split_prop, C * d);
+  ALLOC(split_u, C);
+  ALLOC(split_pending, C);
 #undef ALLOC
   S.theta = e->theta.p;
   S.prob = e->prob.p;
@@ -440,6 +502,11 @@ int alloc_state(mhx_engine* e) {
   S.pool_vec = e->pool_vec.p;
   S.L_pool = e->L_pool.p;
   S.pool_valid = e->pool_valid.p;
+  S.split_prop = e->split_prop.p;
+  S.split_u = e->split_u.p;
+  S.split_pending = e->split_pending.p;
+  S.split_part = nullptr;
+  S.split_slots = 0;
   return MHX_OK;
 }
 
@@ -455,7 +522,34 @@ int count_running(mhx_engine* e, int64_t* n_running) {
 // one timed launch of the fused step kernel
 int launch_steps(mhx_engine* e, int64_t iters, int plain) {
   HIP_TRY(hipEventRecord(e->ev0, e->stream));
-  HIP_TRY(do_adaptive(e, iters, plain));
+  if (e->split_slices > 0) {
+    // split mode: prime (first half of iteration 1), then per iteration the sweep over all
+    // slices and the chain's own launch (second half + first half of the next; the last one
+    // leaves nothing outstanding).  2 * iters + 1 small launches, queued without waiting.
+    // The batch kernel leaves its loop when no chain of the workgroup is running; here the HOST
+    // drives the iterations, so they go out in portions with a look at the chain states between
+    // them (the caller may ask for 2^40 iterations meaning "until done").
+    int64_t left = iters;
+    while (left > 0) {
+      const int64_t now = std::min<int64_t>(left, std::max<int64_t>(e->split_portion, 16));
+      HIP_TRY(do_split_step(e, 0, plain));
+      for (int64_t it = 0; it < now; ++it) {
+        HIP_TRY(do_split_sweep(e));
+        HIP_TRY(do_split_step(e, it + 1 < now ? 1 : 2, plain));
+      }
+      e->launches += 2 * (uint64_t)now + 1;
+      left -= now;
+      if (left > 0) {
+        int64_t running = 0;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        const int rc = count_running(e, &running);
+        if (rc != MHX_OK) return rc;
+        if (running == 0) break;
+      }
+    }
+  } else {
+    HIP_TRY(do_adaptive(e, iters, plain));
+  }
   HIP_TRY(hipEventRecord(e->ev1, e->stream));
   HIP_TRY(hipEventSynchronize(e->ev1));
   float ms = 0.f;

@@ -240,9 +240,73 @@ __device__ __forceinline__ double finish_lik(const FnDesc& f, double s) {
   return s + f.lik_const;
 }
 
+__device__ __forceinline__ double finish_by_lik(const FnDesc& f, double s) {
+  switch (f.lik) {
+    case MHX_LIK_NORMAL: return finish_lik<MHX_LIK_NORMAL>(f, s);
+    case MHX_LIK_NORMAL_CUTOFF: return finish_lik<MHX_LIK_NORMAL_CUTOFF>(f, s);
+    case MHX_LIK_POISSON: return finish_lik<MHX_LIK_POISSON>(f, s);
+    default: return finish_lik<MHX_LIK_EXPR>(f, s);
+  }
+}
+
+// ---- split mode -----------------------------------------------------------------------------
+// With few chains and long datasets one wavefront per chain leaves the GPU idle.  In split mode
+// the likelihood sum of ONE chain is spread over many workgroups: wave `slot` of the launch
+// takes points [p0, p1) of every function, straight from global memory (nothing is shared
+// between the waves of a workgroup here, so no LDS tiles), and writes its partial sum; the
+// chain's own wave then adds the partials in slot order (deterministic) and does everything
+// else of the step.  Per point the arithmetic is sweep()'s; only the grouping of the sum differs,
+// so results agree with the batch kernels to rounding, not bit for bit.
+template <class Model, int LIK, bool FAST>
+__device__ __forceinline__ double sweep_direct(const FnDesc& f, const typename Model::Prep& prep,
+                                               int64_t p0, int64_t p1) {
+  const int l = lane_id();
+  double acc0 = 0.0, acc1 = 0.0;
+  // two 64-point blocks per iteration, the loads of the next pair issued before the arithmetic
+  // of the current one; p0 and p1 are multiples of 128 inside the padded arrays
+  for (int64_t b = p0; b < p1; b += 2 * kWave) {
+    const int64_t i0 = b + l, i1 = b + kWave + l;
+    const double x0 = f.x[i0], x1 = f.x[i1], y0 = f.y[i0], y1 = f.y[i1];
+    double w0 = 0.0, w1 = 0.0, c0 = 0.0, c1 = 0.0;
+    if constexpr (LIK != MHX_LIK_POISSON) { w0 = f.w[i0]; w1 = f.w[i1]; }
+    if constexpr (LIK == MHX_LIK_NORMAL_CUTOFF) { c0 = f.c[i0]; c1 = f.c[i1]; }
+    const double m0 = model_eval<Model, FAST>(prep, x0), m1 = model_eval<Model, FAST>(prep, x1);
+    if constexpr (LIK == MHX_LIK_NORMAL) {
+      const double r0 = __builtin_fma(-m0, w0, y0), r1 = __builtin_fma(-m1, w1, y1);
+      acc0 = __builtin_fma(r0, r0, acc0);
+      acc1 = __builtin_fma(r1, r1, acc1);
+    } else if constexpr (LIK == MHX_LIK_NORMAL_CUTOFF) {
+      const double r0 = __builtin_fma(-m0, w0, y0), r1 = __builtin_fma(-m1, w1, y1);
+      const double t0 = __builtin_fma(-0.5 * r0, r0, c0), t1 = __builtin_fma(-0.5 * r1, r1, c1);
+      acc0 = acc0 + (t0 > -5000.0 ? t0 : -5000.0);
+      acc1 = acc1 + (t1 > -5000.0 ? t1 : -5000.0);
+    } else if constexpr (LIK == MHX_LIK_EXPR) {
+      const double t0 = Model::lik_term(y0, m0, w0), t1 = Model::lik_term(y1, m1, w1);
+      acc0 = acc0 + (i0 < f.n ? t0 : 0.0);
+      acc1 = acc1 + (i1 < f.n ? t1 : 0.0);
+    } else {
+      const double t0 = __builtin_fma(y0, mlog(m0), -m0), t1 = __builtin_fma(y1, mlog(m1), -m1);
+      acc0 = acc0 + (i0 < f.n ? t0 : 0.0);
+      acc1 = acc1 + (i1 < f.n ? t1 : 0.0);
+    }
+  }
+  return wave_sum(acc0 + acc1);
+}
+
 // A problem whose K functions all use one compiled model and likelihood
 template <class Model, int LIK>
 struct FixedSpec {
+  static constexpr bool kSplit = true;  // has loglik_part
+  // partial likelihood sum over points [p0, p1) (split mode; no barriers, one wave)
+  template <class PF>
+  static __device__ __forceinline__ double loglik_part(const FnDesc& f, PF pf, int64_t p0,
+                                                       int64_t p1) {
+    typename Model::Prep prep = Model::prepare(pf, f);
+    if constexpr (model_has_fast<Model>::value) {
+      if (Model::fast_ok(prep)) return sweep_direct<Model, LIK, true>(f, prep, p0, p1);
+    }
+    return sweep_direct<Model, LIK, false>(f, prep, p0, p1);
+  }
   template <class PF>
   static __device__ __forceinline__ double loglik(const FnDesc& f, PF pf, bool active,
                                                   GroupLds& lds, double*) {
@@ -262,6 +326,11 @@ struct FixedSpec {
 
 // Anything else: wave-uniform dispatch on (model, shape, likelihood)
 struct GenericSpec {
+  static constexpr bool kSplit = false;  // models whose parameters live in LDS: batch kernels only
+  template <class PF>
+  static __device__ __forceinline__ double loglik_part(const FnDesc&, PF, int64_t, int64_t) {
+    return 0.0;
+  }
   static __device__ __forceinline__ double logprior(const FnDesc&, const double*, double bt) {
     return bt;
   }
@@ -363,6 +432,29 @@ __device__ __forceinline__ double group_logpost(const ProblemDesc& P, bool activ
     const double v = Spec::loglik(f, pf, active, lds, lds.prm[w]);
     ll = k == 0 ? v : ll + v;
     // Spec::logprior lets a user prior body add terms to bounds-total (M:366-369)
+    const double q = Spec::logprior(f, th, logprior_fn(f, th));
+    lp = k == 0 ? q : lp + q;
+  }
+  *ll_out = ll;
+  *lp_out = lp;
+  return ll + lp;
+}
+
+// split mode: the same value from the partial sums the sweep launch left in S.split_part
+template <class Spec>
+__device__ __forceinline__ double split_logpost(const ProblemDesc& P, const ChainState& S,
+                                                int64_t c, bool active, GroupLds& lds, int w,
+                                                double* ll_out, double* lp_out) {
+  double ll = 0.0, lp = 0.0;
+  const double* th = lds.prop[w];
+  const int l = lane_id();
+  for (int k = 0; k < P.K; ++k) {
+    const FnDesc& f = P.fn[k];
+    const double* part = S.split_part + ((active ? c : 0) * P.K + k) * S.split_slots;
+    double a = 0.0;
+    for (int s = l; s < S.split_slots; s += kWave) a = a + part[s];  // slot order, fixed
+    const double v = finish_by_lik(f, wave_sum(a));
+    ll = k == 0 ? v : ll + v;
     const double q = Spec::logprior(f, th, logprior_fn(f, th));
     lp = k == 0 ? q : lp + q;
   }
@@ -571,9 +663,13 @@ __device__ __forceinline__ void k_step_injected_body(
     const ProblemDesc* __restrict__ Pp, ChainState S, const double* __restrict__ Lin,
     int per_chain_l, const double* __restrict__ z, const double* __restrict__ u,
     const double* __restrict__ T, unsigned char* __restrict__ accepted);
-template <class Spec>
+template <class Spec, bool SPLIT = false>
 __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ Pp, ChainState S,
-                                                RunDesc R, int64_t max_iters, int plain);
+                                                RunDesc R, int64_t max_iters, int plain,
+                                                int mode = 1);
+template <class Spec>
+__device__ __forceinline__ void k_split_sweep_body(const ProblemDesc* __restrict__ Pp,
+                                                   ChainState S);
 
 // Every Spec-dependent kernel is a __device__ body + a thin __global__ template, so that the
 // run-time compiled user-expression kernels (mhx_rtc.cpp) can wrap the same bodies.
@@ -790,9 +886,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_adaptive(const ProblemDesc* __r
                                                        int64_t max_iters, int plain) {
   k_adaptive_body<Spec>(Pp, S, R, max_iters, plain);
 }
-template <class Spec>
+// SPLIT: the iteration is cut where the log-posterior is needed - a launch of this body does the
+// second half of one iteration (judge the outstanding proposal with the partial sums of the
+// sweep launch: mode 1, 2) and / or the first half of the next (end test, shut-down test, new
+// proposal into S.split_prop: mode 0, 1).  mode 0 primes, 1 is the steady state, 2 ends a run
+// of launches with nothing outstanding.
+template <class Spec, bool SPLIT>
 __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ Pp, ChainState S,
-                                                RunDesc R, int64_t max_iters, int plain) {
+                                                RunDesc R, int64_t max_iters, int plain,
+                                                int mode) {
   GroupLds& lds = *reinterpret_cast<GroupLds*>(mhx_lds_raw);
   lds_begin(lds);
   const ProblemDesc& P = *Pp;
@@ -815,8 +917,24 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
   const double factor = (2.38 * 2.38) / (double)d;  // (/ (expt 2.38d0 2) num-params) M:890
   const int64_t age0 = valid ? r.age : 0;
 
-  for (int64_t it = 0; it < max_iters; ++it) {
+  for (int64_t it = 0; SPLIT || it < max_iters; ++it) {
     bool running = valid && r.status == MHX_CHAIN_RUNNING;
+    double thp = 0.0, u = 1.0;
+    bool resumed = false;
+    if constexpr (SPLIT) {
+      resumed = it == 0 && mode != 0;
+      if (!resumed && (it > 1 || (it > 0 && mode == 2))) break;
+    }
+    if (resumed) {
+      // second half of the iteration whose proposal an earlier launch left behind
+      running = running && __builtin_amdgcn_readfirstlane(S.split_pending[valid ? c : 0]) != 0;
+      if (running) {
+        thp = l < d ? S.split_prop[c * d + l] : 0.0;
+        u = uniform_f64(S.split_u[c]);
+        if (l < d) lds.prop[w][l] = thp;
+        if (l == 0) S.split_pending[c] = 0;
+      }
+    } else {
     if (running) {
       if (r.loop_i >= R.n) {  // end test of the do loop, M:904
         r.status = MHX_CHAIN_DONE;
@@ -827,8 +945,10 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
         running = false;
       }
     }
+    if constexpr (SPLIT) {
+      if (valid && l == 0) S.split_pending[c] = 0;
+    }
     if (!__syncthreads_or(running ? 1 : 0)) break;
-    double thp = 0.0, u = 1.0;
     if (running) {
       if (!plain) {
         // M:905-917
@@ -857,8 +977,23 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
       thp = propose(Lc, d, rv, r.th);
       if (l < d) lds.prop[w][l] = thp;
     }
+    if constexpr (SPLIT) {  // hand the proposal to the sweep launch and stop here
+      if (running) {
+        if (l < d) S.split_prop[c * d + l] = thp;
+        if (l == 0) {
+          S.split_u[c] = u;
+          S.split_pending[c] = 1;
+        }
+      }
+      break;
+    }
+    }  // !resumed
     double ll, lp;
-    const double prob1 = group_logpost<Spec>(P, running, lds, w, &ll, &lp);
+    double prob1;
+    if constexpr (SPLIT)
+      prob1 = split_logpost<Spec>(P, S, c, running, lds, w, &ll, &lp);
+    else
+      prob1 = group_logpost<Spec>(P, running, lds, w, &ll, &lp);
     if (!running) continue;
     if (!finite_f64(prob1)) {
       r.status = MHX_CHAIN_FP_TRAP;
@@ -930,6 +1065,43 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     chain_store(S, c, d, r);
     if (l == 0 && r.age != age0) atomicAdd(S.step_counter, (unsigned long long)(r.age - age0));
   }
+}
+
+// split mode, launch 1 of a step: block (slice g, chain c); wave w of it is slot g * waves + w
+template <class Spec>
+__device__ __forceinline__ void k_split_sweep_body(const ProblemDesc* __restrict__ Pp,
+                                                   ChainState S) {
+  __shared__ double sprop[kWavesPerGroup][MHX_MAX_PARAMS];
+  const ProblemDesc& P = *Pp;
+  const int w = wave_in_group(), l = lane_id(), d = P.d;
+  const int64_t c = blockIdx.y;
+  if (__builtin_amdgcn_readfirstlane(S.split_pending[c]) == 0) return;  // nothing to judge
+  const int slot = (int)blockIdx.x * kWavesPerGroup + w;
+  if (l < d) sprop[w][l] = S.split_prop[c * d + l];
+  const double* th = sprop[w];
+  for (int k = 0; k < P.K; ++k) {
+    const FnDesc& f = P.fn[k];
+    auto pf = [&](int j) -> double { return th[f.idx[j]]; };
+    // contiguous chunks of whole 128-point pairs; the arrays are padded past n (mhx_types.hpp)
+    const int64_t pairs = (f.n + 2 * kWave - 1) / (2 * kWave);
+    const int64_t per = (pairs + S.split_slots - 1) / S.split_slots;
+    const int64_t b0 = (int64_t)slot * per, b1 = b0 + per < pairs ? b0 + per : pairs;
+    double v = 0.0;
+    if (b0 < b1) v = Spec::loglik_part(f, pf, b0 * 2 * kWave, b1 * 2 * kWave);
+    if (l == 0) S.split_part[(c * P.K + k) * S.split_slots + slot] = v;
+  }
+}
+template <class Spec>
+__global__ __launch_bounds__(kThreads) void k_split_sweep(const ProblemDesc* __restrict__ Pp,
+                                                          ChainState S) {
+  k_split_sweep_body<Spec>(Pp, S);
+}
+// split mode, launch 2 of a step (and the priming / closing launches): see k_adaptive_body
+template <class Spec>
+__global__ __launch_bounds__(kThreads) void k_split_step(const ProblemDesc* __restrict__ Pp,
+                                                         ChainState S, RunDesc R, int mode,
+                                                         int plain) {
+  k_adaptive_body<Spec, true>(Pp, S, R, 1, plain, mode);
 }
 
 // Initial L of M:896-901 when the caller gave none.

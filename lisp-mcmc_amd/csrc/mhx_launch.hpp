@@ -49,6 +49,13 @@ struct Family {
   hipError_t (*pool_reduce)(hipStream_t st, const ChainState& S);
   hipError_t (*pool_factor)(hipStream_t st, const ChainState& S);
   hipError_t (*modify)(hipStream_t st, const ChainState& S, int action, int64_t n);
+  // split mode (mhx_kernels.hpp): the partial sums of every pending proposal over `slices`
+  // workgroups per chain, and the two halves of the loop iteration around them
+  bool (*split_capable)(int spec);
+  hipError_t (*split_sweep)(int spec, hipStream_t st, const ProblemDesc* P, const ChainState& S,
+                            int slices);
+  hipError_t (*split_step)(int spec, hipStream_t st, const ProblemDesc* P, const ChainState& S,
+                           const RunDesc& R, int mode, int plain);
 };
 
 const Family& family_w8();

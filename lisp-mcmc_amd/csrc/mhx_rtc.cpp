@@ -164,7 +164,7 @@ int rtc_prepare_expr(const std::string& expr, const std::vector<std::string>& na
 // ---- source generation --------------------------------------------------------------------------
 static std::string generate(const std::vector<UserExpr>& models,
                             const std::vector<UserExpr>& priors, bool builtin_fallback,
-                            int min_waves, int threads) {
+                            int min_waves, int threads, bool with_split = false) {
   std::ostringstream s;
   s << "#define MHX_USER_THREADS " << threads << "\n"
     << "#include \"mhx_kernels.hpp\"\n"
@@ -243,6 +243,18 @@ static std::string generate(const std::vector<UserExpr>& models,
             ? "      default: return GenericSpec::loglik(f, pf, active, lds, scratch);\n"
             : "      default: (void)scratch; return 0.0;  // every function has a slot\n")
     << "    }\n  }\n"
+       "  static constexpr bool kSplit = true;\n"
+       "  template <class PF>\n"
+       "  static __device__ __forceinline__ double loglik_part(const FnDesc& f, PF pf, int64_t p0,\n"
+       "                                                       int64_t p1) {\n"
+       "    switch (f.user_slot) {\n";
+  for (size_t m = 0; m < models.size(); ++m) {
+    const int lik = models[m].lik;
+    if (with_split && lik >= 0 && lik <= 3)
+      s << "      case " << m << ": return FixedSpec<UserModel" << m << ", " << kLikName[lik]
+        << ">::loglik_part(f, pf, p0, p1);\n";
+  }
+  s << "      default: return 0.0;\n    }\n  }\n"
        "  static __device__ __forceinline__ double logprior(const FnDesc& f, const double* th,\n"
        "                                                    double bounds_total) {\n"
        "    switch (f.prior_slot) {\n";
@@ -276,6 +288,13 @@ static std::string generate(const std::vector<UserExpr>& models,
     << ") void mhx_user_adaptive(\n"
        "    const ProblemDesc* P, ChainState S, RunDesc R, int64_t max_iters, int plain) {\n"
        "  k_adaptive_body<UserSpec>(P, S, R, max_iters, plain);\n}\n";
+  if (with_split)
+    s << "extern \"C\" __global__ __launch_bounds__(MHX_USER_THREADS) void mhx_user_split_sweep(\n"
+         "    const ProblemDesc* P, ChainState S) {\n"
+         "  k_split_sweep_body<UserSpec>(P, S);\n}\n"
+         "extern \"C\" __global__ __launch_bounds__(MHX_USER_THREADS) void mhx_user_split_step(\n"
+         "    const ProblemDesc* P, ChainState S, RunDesc R, int mode, int plain) {\n"
+         "  k_adaptive_body<UserSpec, true>(P, S, R, 1, plain, mode);\n}\n";
   return s.str();
 }
 
@@ -353,14 +372,14 @@ static void cache_store(const std::string& key, const std::vector<char>& code) {
 }
 
 static int build_once(const std::vector<UserExpr>& models, const std::vector<UserExpr>& priors,
-                      bool builtin_fallback, const Family& fam, int min_waves, UserProgram* prog,
-                      std::string* err) {
+                      bool builtin_fallback, bool with_split, const Family& fam, int min_waves,
+                      UserProgram* prog, std::string* err) {
   Hiprtc& r = rtc();
   if (!r.ok) {
     *err = "libhiprtc.so could not be loaded: expression models need ROCm's hiprtc";
     return -1;
   }
-  prog->source = generate(models, priors, builtin_fallback, min_waves, fam.threads);
+  prog->source = generate(models, priors, builtin_fallback, min_waves, fam.threads, with_split);
   if (const char* dump = getenv("MHX_RTC_DUMP")) {  // the generated translation unit, for study
     if (FILE* fp = fopen(dump, "w")) {
       fputs(prog->source.c_str(), fp);
@@ -446,6 +465,20 @@ static int build_once(const std::vector<UserExpr>& models, const std::vector<Use
       return -1;
     }
   }
+  prog->has_split = false;
+  if (with_split) {
+    he = hipModuleGetFunction(&prog->f_split_sweep, prog->module, "mhx_user_split_sweep");
+    if (he == hipSuccess)
+      he = hipModuleGetFunction(&prog->f_split_step, prog->module, "mhx_user_split_step");
+    if (he == hipSuccess)
+      he = hipFuncSetAttribute(reinterpret_cast<const void*>(prog->f_split_step),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)fam.lds_bytes);
+    if (he != hipSuccess) {
+      *err = std::string("split-mode module functions: ") + hipGetErrorString(he);
+      return -1;
+    }
+    prog->has_split = true;
+  }
   prog->fam = &fam;
   return 0;
 }
@@ -456,24 +489,25 @@ static int build_once(const std::vector<UserExpr>& models, const std::vector<Use
 // controller's own code uses - it is rebuilt for 2 waves per SIMD (256 VGPRs).
 // MHX_RTC_MIN_WAVES=2|4 pins the choice.
 int rtc_build(const std::vector<UserExpr>& models, const std::vector<UserExpr>& priors,
-              bool builtin_fallback, const Family& fam, UserProgram* prog, std::string* err) {
+              bool builtin_fallback, bool with_split, const Family& fam, UserProgram* prog,
+              std::string* err) {
   int pinned = 0;
   if (const char* s = getenv("MHX_RTC_MIN_WAVES")) pinned = atoi(s);
   if (pinned == 2 || pinned == 4)
-    return build_once(models, priors, builtin_fallback, fam, pinned, prog, err);
-  int rc = build_once(models, priors, builtin_fallback, fam, 4, prog, err);
+    return build_once(models, priors, builtin_fallback, with_split, fam, pinned, prog, err);
+  int rc = build_once(models, priors, builtin_fallback, with_split, fam, 4, prog, err);
   if (rc != 0) return rc;
   int scratch = 0;
   if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, prog->f_adaptive) !=
           hipSuccess ||
       scratch <= 128)
     return 0;
-  return build_once(models, priors, builtin_fallback, fam, 2, prog, err);
+  return build_once(models, priors, builtin_fallback, with_split, fam, 2, prog, err);
 }
 
 std::shared_ptr<UserProgram> rtc_get(const std::vector<UserExpr>& models,
                                      const std::vector<UserExpr>& priors, bool builtin_fallback,
-                                     const Family& fam, std::string* err) {
+                                     bool with_split, const Family& fam, std::string* err) {
   // The newest kCap modules stay loaded for the life of the process (an engine that is created
   // again for the same problem - a loop over datasets, a test suite - does not compile again).
   // The containers are leaked on purpose: unloading modules from a static destructor would race
@@ -485,12 +519,13 @@ std::shared_ptr<UserProgram> rtc_get(const std::vector<UserExpr>& models,
   int dev = 0;
   (void)hipGetDevice(&dev);
   const std::string key = "dev" + std::to_string(dev) + "|" +
-                          generate(models, priors, builtin_fallback, 4, fam.threads);
+                          generate(models, priors, builtin_fallback, 4, fam.threads, with_split);
   std::lock_guard<std::mutex> lock(mu);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   std::shared_ptr<UserProgram> prog(new UserProgram());
-  if (rtc_build(models, priors, builtin_fallback, fam, prog.get(), err) != 0) return nullptr;
+  if (rtc_build(models, priors, builtin_fallback, with_split, fam, prog.get(), err) != 0)
+    return nullptr;
   if (order.size() >= kCap) {  // engines still using the oldest one keep it alive themselves
     cache.erase(order.front());
     order.erase(order.begin());
@@ -527,6 +562,22 @@ hipError_t rtc_launch_step_injected(const UserProgram& p, hipStream_t st, const 
                   (void*)&u, (void*)&T, (void*)&accepted};
   return hipModuleLaunchKernel(p.f_step, grid_for(p, S.n_chains), 1, 1, (unsigned)p.fam->threads, 1, 1,
                                (unsigned)p.fam->lds_bytes, st, args, nullptr);
+}
+hipError_t rtc_launch_split_sweep(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                                  const ChainState& S, int slices) {
+  ChainState s = S;
+  void* args[] = {(void*)&P, (void*)&s};
+  return hipModuleLaunchKernel(p.f_split_sweep, (unsigned)slices, (unsigned)S.n_chains, 1,
+                               (unsigned)p.fam->threads, 1, 1, 0, st, args, nullptr);
+}
+hipError_t rtc_launch_split_step(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                                 const ChainState& S, const RunDesc& R, int mode, int plain) {
+  ChainState s = S;
+  RunDesc r = R;
+  void* args[] = {(void*)&P, (void*)&s, (void*)&r, (void*)&mode, (void*)&plain};
+  return hipModuleLaunchKernel(p.f_split_step, grid_for(p, S.n_chains), 1, 1,
+                               (unsigned)p.fam->threads, 1, 1, (unsigned)p.fam->lds_bytes, st, args,
+                               nullptr);
 }
 hipError_t rtc_launch_adaptive(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                                const ChainState& S, const RunDesc& R, int64_t max_iters,

@@ -31,6 +31,8 @@ struct UserExpr {
 struct UserProgram {
   hipModule_t module = nullptr;
   hipFunction_t f_logpost = nullptr, f_init = nullptr, f_step = nullptr, f_adaptive = nullptr;
+  hipFunction_t f_split_sweep = nullptr, f_split_step = nullptr;  // only with has_split
+  bool has_split = false;
   const Family* fam = nullptr;  // the kernel family (workgroup shape) the module was built for
   std::string source, log;
   ~UserProgram();
@@ -47,12 +49,13 @@ int rtc_prepare_expr(const std::string& expr, const std::vector<std::string>& na
 // functions with ahead-of-time models, so the generic dispatcher must be part of the kernels.
 // Returns 0 or fills *err.
 int rtc_build(const std::vector<UserExpr>& models, const std::vector<UserExpr>& priors,
-              bool builtin_fallback, const Family& fam, UserProgram* prog, std::string* err);
+              bool builtin_fallback, bool with_split, const Family& fam, UserProgram* prog,
+              std::string* err);
 // The same through a process-wide cache (keyed by device and generated source): engines that
 // describe the same problem share one compiled module.  Returns nullptr and fills *err on error.
 std::shared_ptr<UserProgram> rtc_get(const std::vector<UserExpr>& models,
                                      const std::vector<UserExpr>& priors, bool builtin_fallback,
-                                     const Family& fam, std::string* err);
+                                     bool with_split, const Family& fam, std::string* err);
 
 hipError_t rtc_launch_logpost(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                               const double* theta, int64_t n, double* out, double* parts);
@@ -62,6 +65,10 @@ hipError_t rtc_launch_step_injected(const UserProgram& p, hipStream_t st, const 
                                     const ChainState& S, const double* L, int per_chain_l,
                                     const double* z, const double* u, const double* T,
                                     unsigned char* accepted);
+hipError_t rtc_launch_split_sweep(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                                  const ChainState& S, int slices);
+hipError_t rtc_launch_split_step(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                                 const ChainState& S, const RunDesc& R, int mode, int plain);
 hipError_t rtc_launch_adaptive(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                                const ChainState& S, const RunDesc& R, int64_t max_iters,
                                int plain);

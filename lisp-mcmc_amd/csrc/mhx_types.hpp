@@ -93,6 +93,15 @@ struct ChainState {
   double* L_pool;
   int32_t* pool_valid;
   unsigned long long* step_counter;  // chain-steps taken by all chains (device atomic)
+  // split mode (few chains, long datasets: one chain's likelihood sum is spread over many
+  // workgroups, mhx_kernels.hpp "split mode"): the outstanding proposal of every chain and the
+  // partial sums of its functions, one per (slice, wave) slot
+  double* split_prop;      // [C][d]
+  double* split_u;         // [C] the accept uniform drawn with the proposal
+  int32_t* split_pending;  // [C] 1: split_prop / split_u hold a proposal to be judged
+  double* split_part;      // [C][K][split_slots]
+  int32_t split_slots;
+  int32_t split_pad_;
 };
 
 struct RunDesc {

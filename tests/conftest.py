@@ -26,3 +26,13 @@ def orc():
     import oraclelib
     oraclelib.lib()
     return oraclelib
+
+
+@pytest.fixture(autouse=True)
+def _batch_kernels_unless_the_test_is_about_split_mode(request, monkeypatch):
+    """Small batches on long datasets run in split mode by default (csrc/mhx_kernels.hpp), whose
+    sums are grouped differently from the batch kernels'.  The parity suites were written about
+    the batch kernels - several compare small engines with large ones bit for bit - so they pin
+    MHX_SPLIT=0; tests/test_gpu_split.py manages the switch itself."""
+    if request.module.__name__ != "test_gpu_split":
+        monkeypatch.setenv("MHX_SPLIT", "0")
