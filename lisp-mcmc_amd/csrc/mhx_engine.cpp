@@ -119,6 +119,12 @@ struct mhx_engine {
   // split mode (few chains, long datasets): 0 = batch kernels, else workgroups per chain
   int split_slices = 0;
   int64_t split_portion = 512;  // iterations queued between two looks at the chain states
+  // one portion of split-mode launches captured as a HIP graph (replayed; the kernel arguments -
+  // chain state pointers, run description - are frozen in it, so it is dropped whenever the run or
+  // the problem changes): fewer microseconds per launch than issuing 2 N + 1 kernels one by one
+  hipGraphExec_t split_graph = nullptr;
+  int64_t split_graph_iters = 0;
+  int split_graph_plain = -1;
   DevBuf<double> split_prop, split_u, split_part;
   DevBuf<int32_t> split_pending;
   bool chains_ready = false;
@@ -139,6 +145,8 @@ struct mhx_engine {
 };
 
 namespace {
+
+void drop_split_graph(mhx_engine* e);
 
 int use_device(mhx_engine* e) {
   HIP_TRY(hipSetDevice(e->device));
@@ -211,6 +219,7 @@ const Family& choose_family(const mhx_engine* e) {
 
 int finalize_problem(mhx_engine* e) {
   if (!e->problem_dirty) return MHX_OK;
+  drop_split_graph(e);
   for (int k = 0; k < e->P.K; ++k) {
     if (!e->fn_set[k]) return fail(MHX_ESTATE, "function %d was never set (mhx_set_function)", k);
     if (!e->data[k].set) return fail(MHX_ESTATE, "dataset %d was never set (mhx_set_dataset)", k);
@@ -510,6 +519,13 @@ int alloc_state(mhx_engine* e) {
   return MHX_OK;
 }
 
+void drop_split_graph(mhx_engine* e) {
+  if (e->split_graph) (void)hipGraphExecDestroy(e->split_graph);
+  e->split_graph = nullptr;
+  e->split_graph_iters = 0;
+  e->split_graph_plain = -1;
+}
+
 int count_running(mhx_engine* e, int64_t* n_running) {
   std::vector<int32_t> st((size_t)e->cfg.n_chains);
   HIP_TRY(hipMemcpy(st.data(), e->status.p, st.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -532,11 +548,41 @@ int launch_steps(mhx_engine* e, int64_t iters, int plain) {
     int64_t left = iters;
     while (left > 0) {
       const int64_t now = std::min<int64_t>(left, std::max<int64_t>(e->split_portion, 16));
-      HIP_TRY(do_split_step(e, 0, plain));
-      for (int64_t it = 0; it < now; ++it) {
-        HIP_TRY(do_split_sweep(e));
-        HIP_TRY(do_split_step(e, it + 1 < now ? 1 : 2, plain));
+      auto issue = [&](int64_t count) -> hipError_t {
+        hipError_t he = do_split_step(e, 0, plain);
+        for (int64_t it = 0; it < count && he == hipSuccess; ++it) {
+          he = do_split_sweep(e);
+          if (he == hipSuccess) he = do_split_step(e, it + 1 < count ? 1 : 2, plain);
+        }
+        return he;
+      };
+      const char* ng = getenv("MHX_NO_GRAPH");
+      const bool use_graph = !(ng && atoi(ng) != 0) && now >= 16;
+      bool done = false;
+      if (use_graph) {
+        if (!e->split_graph || e->split_graph_iters != now || e->split_graph_plain != plain) {
+          drop_split_graph(e);
+          hipGraph_t g = nullptr;
+          if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const hipError_t he = issue(now);
+            const hipError_t ce = hipStreamEndCapture(e->stream, &g);
+            if (he == hipSuccess && ce == hipSuccess && g &&
+                hipGraphInstantiate(&e->split_graph, g, nullptr, nullptr, 0) == hipSuccess) {
+              e->split_graph_iters = now;
+              e->split_graph_plain = plain;
+            } else {
+              e->split_graph = nullptr;
+            }
+            if (g) (void)hipGraphDestroy(g);
+          }
+          (void)hipGetLastError();
+        }
+        if (e->split_graph) {
+          HIP_TRY(hipGraphLaunch(e->split_graph, e->stream));
+          done = true;
+        }
       }
+      if (!done) HIP_TRY(issue(now));
       e->launches += 2 * (uint64_t)now + 1;
       left -= now;
       if (left > 0) {
@@ -683,6 +729,7 @@ void mhx_destroy(mhx_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  drop_split_graph(e);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -973,6 +1020,7 @@ int mhx_adaptive_begin(mhx_engine* e, const mhx_run_opts* o) {
   int rc = use_device(e);
   if (rc != MHX_OK) return rc;
   if ((rc = finalize_problem(e)) != MHX_OK) return rc;
+  drop_split_graph(e);  // the run description is an argument frozen into the captured launches
   const int d = e->P.d;
   RunDesc& R = e->R;
   R.n = o->n;                                       // (floor n) M:866
@@ -1071,6 +1119,7 @@ int mhx_many_steps(mhx_engine* e, int64_t n, const double* L, int per_chain_l) {
   int rc = use_device(e);
   if (rc != MHX_OK) return rc;
   if ((rc = finalize_problem(e)) != MHX_OK) return rc;
+  drop_split_graph(e);
   const size_t C = (size_t)e->cfg.n_chains, dd = (size_t)e->P.d * e->P.d;
   if (per_chain_l) {
     HIP_TRY(hipMemcpy(e->L.p, L, C * dd * sizeof(double), hipMemcpyHostToDevice));
