@@ -557,7 +557,8 @@ int launch_steps(mhx_engine* e, int64_t iters, int plain) {
         return he;
       };
       const char* ng = getenv("MHX_NO_GRAPH");
-      const bool use_graph = !(ng && atoi(ng) != 0) && now >= 16;
+      // (only whole portions: a remainder of another length would mean capturing again)
+      const bool use_graph = !(ng && atoi(ng) != 0) && now == e->split_portion;
       bool done = false;
       if (use_graph) {
         if (!e->split_graph || e->split_graph_iters != now || e->split_graph_plain != plain) {
