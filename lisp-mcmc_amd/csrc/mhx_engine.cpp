@@ -196,6 +196,9 @@ int choose_split(const mhx_engine* e, const Family& fam, bool capable) {
   // 256 chains x4: 4.4e6 against 1.2e6, one chain x24: 6.0e4 against 7.5e3)
   const int64_t batch_groups = (C + W - 1) / W;
   if (batch_groups >= 256) return 0;
+  // two launches cost about 14 us per iteration: the fused batch kernel is quicker than that up
+  // to roughly a dozen 1024-point tiles
+  if (by_data < 4) return 0;
   const int64_t slices = std::min<int64_t>(std::max<int64_t>(2, std::min<int64_t>(1024 / C, 24)),
                                            by_data);
   return slices >= 2 ? (int)slices : 0;

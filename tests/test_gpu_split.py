@@ -49,7 +49,7 @@ def walk(e, th0, n, l0=None, plain=False):
 CASES = [
     ("two_peak", lambda: pb.two_peak(n=30000, seed=3), None),
     ("poisson", lambda: pb.poisson_peaks(n=24000, seed=4), 0.002),
-    ("global_fit", lambda: pb.global_fit(n_each=9000, n_sets=3, seed=5), None),
+    ("global_fit", lambda: pb.global_fit(n_each=20000, n_sets=3, seed=5), None),
 ]
 
 
