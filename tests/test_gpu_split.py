@@ -133,3 +133,82 @@ def test_split_mode_is_chosen_by_batch_and_dataset_size(mhx):
     e, name = engine(mhx, s_long, 8, None, adapt_mode=mhx.capi.ADAPT_POOLED)
     assert "split" not in name
     e.close()
+
+
+def _ragged_global_fit(seed=3):
+    """4 functions sharing 10 parameters, lengths 1 / 700 / 40000 / 17000: in split mode the short
+    ones occupy a single slot, the long ones all of them"""
+    rng = np.random.default_rng(seed)
+    th = np.array([0.4, 1.1, 0.5, 0.08, 0.3, 0.2, -0.1, 0.9, 0.25, 0.06])
+    s = pb.Spec(10)
+    for k, (n, model, shape, idx) in enumerate([
+            (1, pb.POLY, (), [4, 5]), (700, pb.POLY, (), [4, 5, 6]),
+            (40000, pb.GAUSS, (1, 1), [0, 1, 2, 3]), (17000, pb.LORENTZ, (1, 1), [0, 7, 8, 9])]):
+        x = np.sort(rng.uniform(0, 1, n))
+        sig = rng.uniform(0.05, 0.2, n)
+        y = pb.model_eval_np(model, shape, th[idx], x) + sig * rng.standard_normal(n)
+        s.add(model, shape, idx, x, y, sig, pb.CUTOFF if k == 1 else pb.NORMAL,
+              (idx, th[idx] - 1.0, th[idx] + 1.0))
+    s.theta_star = th
+    return s
+
+
+def test_split_run_time_specialised_ragged_global_fit(mhx, orc):
+    s = _ragged_global_fit()
+    C_, n = 2, 900
+    th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=4)
+    batch, nb = engine(mhx, s, C_, 0, seed=3)
+    split, ns = engine(mhx, s, C_, None, seed=3)
+    assert "rtc[" in ns and "split x" in ns and "split" not in nb
+    l0 = np.diag(np.full(10, 0.004))
+    sb, stb, _ = walk(batch, th0, n, l0)
+    ss, sts, _ = walk(split, th0, n, l0)
+    assert np.array_equal(stb, sts) and np.array_equal(sb["age"], ss["age"])
+    op = s.oracle(orc)
+    for c in range(C_):
+        ref = op.logpost(ss["theta"][c])
+        assert abs(ss["logpost"][c] - ref) <= REL * op.abs_terms(ss["theta"][c]) + 1e-5
+    assert sum(int(np.array_equal(sb["theta"][c], ss["theta"][c])) for c in range(C_)) >= C_ - 1
+    batch.close()
+    split.close()
+
+
+def test_split_with_expression_likelihood(mhx):
+    rng = np.random.default_rng(6)
+    n = 50000
+    x = np.linspace(0, 1, n)
+    lam = 30 + 80 * np.exp(-((x - 0.4) / 0.1) ** 2)
+    y = rng.poisson(lam).astype(float)
+    model = "(lambda (x &key bg a mu w &allow-other-keys) (+ bg (* a (exp (- (expt (/ (- x mu) w) 2))))))"
+    lik = mhx.create_log_liklihood_function(
+        "(lambda (y model error) (declare (ignore error)) (- (* y (log model)) model))")
+    params = [":bg", 28.0, ":a", 85.0, ":mu", 0.41, ":w", 0.105]
+    ws = []
+    for split in ("0", None):
+        if split is None:
+            os.environ.pop("MHX_SPLIT", None)
+        else:
+            os.environ["MHX_SPLIT"] = split
+        try:
+            w = mhx.walker_create(function=mhx.models.lisp(model), data=[x, y], params=params,
+                                  log_liklihood=lik, seed=3)
+            w.engine.kernel_name()
+        finally:
+            os.environ.pop("MHX_SPLIT", None)
+        ws.append(w)
+    assert "expr:expr" in ws[1].engine.kernel_name() and "split x" in ws[1].engine.kernel_name()
+    l0 = np.diag(0.002 * np.array(params[1::2]))
+    for w in ws:
+        mhx.walker_adaptive_steps_full(w, n=1000, temperature=10, auto=":prob-settle", l_matrix=l0)
+    a, b = ws[0].engine.state(), ws[1].engine.state()
+    assert a["age"][0] == b["age"][0]
+    # one flipped accept test sends two walks apart for good, so the walks are not compared with
+    # each other: each engine's stored log-posterior must be what the batch kernel (mhx_logpost)
+    # and numpy say at the stored position
+    for st, w in ((a, ws[0]), (b, ws[1])):
+        th = st["theta"][0]
+        m = th[0] + th[1] * np.exp(-((x - th[2]) / th[3]) ** 2)
+        ref = float(np.sum(y * np.log(m) - m))
+        assert abs(st["logpost"][0] - ref) <= 1e-11 * float(np.sum(np.abs(y * np.log(m)) + m))
+        assert abs(w.engine.logpost(th[None, :])[0] - st["logpost"][0]) <= 1e-11 * abs(ref)
+    assert abs(b["theta"][0][2] - 0.4) < 0.02
