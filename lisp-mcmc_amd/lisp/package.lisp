@@ -27,4 +27,4 @@
    #:expr-model #:prior-bounds-let-amd #:form->c #:bounds-total
    #:create-log-liklihood-function-amd #:log-normal
    ;; engine-level extras
-   #:walker-n-chains #:walker-chain-status #:mhx-error #:mhx-error-code #:mhx-error-message))
+   #:walker-n-chains #:walker-chain-status #:walker-kernel-name #:mhx-error #:mhx-error-code #:mhx-error-message))

@@ -236,6 +236,11 @@ set that steps as one batch."
       (with-c-call (check (%mhx-get-chain-status e st (cffi:null-pointer))))
       (loop for c below n collect (cffi:mem-aref st :int32 c)))))
 
+(defun walker-kernel-name (walker)
+  "Which kernels serve this walker's problem, e.g. \"w8/lorder_normal\" or
+\"w8/rtc[expr:normal] split x24\" (mhx_kernel_name)."
+  (with-c-call (%mhx-kernel-name (engine-of walker))))
+
 (defun %trace (walker chain take)
   "newest-first list of walker-steps, (walker-get :get :steps :take take)"
   (let* ((e (engine-of walker)) (d (walker-n-params walker))
