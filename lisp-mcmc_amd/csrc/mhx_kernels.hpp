@@ -64,6 +64,10 @@ __device__ __forceinline__ void tile_dma(const FnDesc& f, int64_t t, GroupLds& l
                                      (lds_ptr_t)&lds.tiles[buf][3][wbase], 16, 0, 0);
 }
 
+template <bool B>
+struct BoolC {
+  static constexpr bool value = B;
+};
 template <unsigned M>
 struct CMask {
   constexpr operator unsigned() const { return M; }
@@ -110,8 +114,11 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
       // One tile.  `mk` is the set of Gaussian peaks to evaluate: a run-time value, or a CMask<M>
       // whose value is a compile-time constant once the lambda is inlined - the per-peak tests
       // in PeaksModel::eval then fold away and each variant is straight-line code.
-      auto tile_body = [&](auto mk) {
+      auto tile_body_m = [&](auto mk, auto whole) {
         const unsigned mask = mk;
+        // whole tile = every point is data: the pad test of the Poisson / expression
+        // likelihoods (compare + select per point) is only compiled into the ragged variant
+        constexpr bool kWhole = decltype(whole)::value;
         // P points per lane and iteration: point i of iteration it is element (it*P + i)*64 + l
         // of the tile.  Software-pipelined: the LDS reads of the next P points are issued before
         // the dependent fp64 chains of the current ones, so no wave waits on lgkmcnt.  P = 2
@@ -183,11 +190,11 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
                 // (funcall log-liklihood-function y (apply fn x params) stddev) M:415: the tiles
                 // hold y and sigma as given; pads masked
                 const double tt = Model::lik_term(y[i], m[i], wv[i]);
-                acc = acc + (gi < f.n ? tt : 0.0);
+                acc = acc + ((kWhole || gi < f.n) ? tt : 0.0);
               } else {
                 // (- (* k (log lambda)) lambda ...) M:383; pads masked (no neutral pad exists)
                 const double tt = __builtin_fma(y[i], tlog(m[i], (lds_cdptr_t)lds.logtab), -m[i]);
-                acc = acc + (gi < f.n ? tt : 0.0);
+                acc = acc + ((kWhole || gi < f.n) ? tt : 0.0);
               }
             }
 #pragma unroll
@@ -198,6 +205,16 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
               cv[i] = cn[i];
             }
           }
+        }
+      };
+      auto tile_body = [&](auto mk) {
+        if constexpr (LIK == MHX_LIK_POISSON || LIK == MHX_LIK_EXPR) {
+          if (gbase + kTilePoints <= f.n)
+            tile_body_m(mk, BoolC<true>{});
+          else
+            tile_body_m(mk, BoolC<false>{});
+        } else {
+          tile_body_m(mk, BoolC<true>{});  // neutral pads: nothing to test
         }
       };
       // Gaussian peaks that cannot change any sum of this tile by even one bit are left out
