@@ -437,9 +437,18 @@ __device__ const double kLogTab[128][2] = {
     {0x1.756cac1d7dd05p-1, 0x1.432ef2a76f800p-2},
 };
 typedef __attribute__((address_space(3))) const double* lds_cdptr_t;
-__device__ __forceinline__ double tlog(double x, lds_cdptr_t tab) {
+// a3: the constant 1/5 of the polynomial handed in from a VGPR the caller keeps alive across its
+// loop (tlog_a3()): fma(r, A4, A3) reads two constants and only one may come from the scalar
+// file - otherwise the compiler copies one into the accumulator before a v_fmac, every call
+constexpr double kTlogA3 = 0x1.999999999999ap-3;
+__device__ __forceinline__ double tlog_a3() {
+  double v = kTlogA3;
+  asm volatile("" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ double tlog(double x, lds_cdptr_t tab, double A3 = kTlogA3) {
   const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
-  const double A1 = 0x1.5555555555555p-2, A3 = 0x1.999999999999ap-3, A4 = -0x1.5555555555555p-3;
+  const double A1 = 0x1.5555555555555p-2, A4 = -0x1.5555555555555p-3;
   const unsigned long long b = (unsigned long long)__double_as_longlong(x);
   const unsigned hx = (unsigned)(b >> 32), lx = (unsigned)b;
   const unsigned th = hx - 0x3FE60000u;  // high word of bits(x) - OFF (OFF's low word is 0)

@@ -84,6 +84,8 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
   const int w = wave_in_group();
   const int64_t nt = f.n_tiles;
   double acc0 = 0.0, acc1 = 0.0;
+  const double log_a3 = tlog_a3();  // (Poisson) a constant of tlog() pinned in a VGPR
+  (void)log_a3;
   unsigned tile_masks = ~0u;  // lane i: which peaks tile (t & ~63) + i needs (PeaksModel::tile_mask)
   if (nt == 0) return 0.0;
   // A problem with ONE function of ONE tile (test.lisp's 334 points) walked by a single
@@ -193,7 +195,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
                 acc = acc + ((kWhole || gi < f.n) ? tt : 0.0);
               } else {
                 // (- (* k (log lambda)) lambda ...) M:383; pads masked (no neutral pad exists)
-                const double tt = __builtin_fma(y[i], tlog(m[i], (lds_cdptr_t)lds.logtab), -m[i]);
+                const double tt = __builtin_fma(y[i], tlog(m[i], (lds_cdptr_t)lds.logtab, log_a3), -m[i]);
                 acc = acc + ((kWhole || gi < f.n) ? tt : 0.0);
               }
             }
