@@ -25,6 +25,12 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# fp64 vector peak: 256 CUs x 4 SIMDs, one wave64 fp64 instruction per SIMD every 4 cycles,
+# 2.4 GHz max clock, an fma = 2 flop x 64 lanes -> 78.6 TFLOP/s (MI355X_MICROARCH.md: half the
+# 157.3 TFLOP/s fp32 vector peak)
+N_SIMD, CLOCK_HZ, CYCLES_PER_F64_INSTR = 1024, 2.4e9, 4
+FP64_VALU_PEAK_TFLOPS = N_SIMD * CLOCK_HZ / CYCLES_PER_F64_INSTR * 128 / 1e12
+ROUND_TAG = "r02"  # profiles/<tag>_<workload>_s<steps>_w<warmup>_summary.json
 
 
 def synth_workload(name, rng_key=0x5EED0001):
@@ -92,23 +98,57 @@ def b_alg(spec, b_pt):
     return sum(len(x) for (x, _, _, _) in spec.data) * b_pt + 8 * d * d + 16 * d + 16
 
 
-def cpu_baseline(spec, theta0, budget_s, n_adapt):
-    """the oracle (CPU restatement of the reference, faithful serial sums, libm) on ONE host
-    core, same workload, bounded sample"""
+def cpu_baseline(spec, theta0s, budget_s, n_adapt, threads, l0=None):
+    """the oracle (CPU restatement of the reference, faithful serial sums, libm) on `threads`
+    host cores, same workload, bounded sample: thread i walks chain i (the reference's own way
+    of running many walkers is a list of independent ones, mcmc-fitting.lisp:1029-1033); the
+    ctypes calls release the GIL, so the threads run in parallel.  Returns (chain-steps/s summed
+    over the threads, steps, seconds)."""
+    import threading
     import oraclelib as orc
     op = spec.oracle(orc)
-    w = orc.Walker(op, theta0)
-    w.adaptive_begin(n_adapt, 10.0, 1, seed=0x5EED0003, chain_id=0)
-    steps, t0 = 0, time.perf_counter()
-    chunk = 1
-    while True:
-        w.adaptive_advance(chunk)
-        steps += chunk
-        el = time.perf_counter() - t0
-        if el >= budget_s or w.status != orc.RUNNING:
-            break
-        chunk = max(1, min(64, int(chunk * 2)))
-    return steps / el, steps, el
+    done = [0] * threads
+    t_end = [0.0] * threads
+    start = threading.Barrier(threads + 1)
+
+    def walk(i):
+        w = orc.Walker(op, theta0s[i % len(theta0s)])
+        w.adaptive_begin(n_adapt, 10.0, 1, l_matrix=l0, seed=0x5EED0003, chain_id=i)
+        start.wait()
+        t0 = time.perf_counter()
+        chunk = 1
+        while True:
+            w.adaptive_advance(chunk)
+            done[i] += chunk
+            if time.perf_counter() - t0 >= budget_s or w.status != orc.RUNNING:
+                break
+            chunk = max(1, min(64, chunk * 2))
+        t_end[i] = time.perf_counter()
+
+    ts = [threading.Thread(target=walk, args=(i,)) for i in range(threads)]
+    for t in ts:
+        t.start()
+    start.wait()
+    t0 = time.perf_counter()
+    for t in ts:
+        t.join()
+    el = max(t_end) - t0
+    return sum(done) / el, sum(done), el
+
+
+def load_profile(workload, steps, warmup):
+    """the committed rocprofv3 summary of this command (tools/run_profile.sh), or the nearest
+    one of the same workload; (summary, file name, exact match?)"""
+    import glob
+    exact = os.path.join(ROOT, "profiles", "%s_%s_s%d_w%d_summary.json" % (ROUND_TAG, workload, steps, warmup))
+    cands = [exact] if os.path.exists(exact) else sorted(
+        glob.glob(os.path.join(ROOT, "profiles", "%s_%s_s*_summary.json" % (ROUND_TAG, workload))))
+    for f in cands:
+        try:
+            return json.load(open(f)), os.path.basename(f), f == exact
+        except Exception:  # a malformed summary must not break the benchmark
+            continue
+    return None, None, False
 
 
 def main():
@@ -179,24 +219,28 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Every launch of the step kernel - warm-up and timed alike - runs the same number of loop
-    # iterations, so that rocprofv3's per-kernel average duration (profiles/) is directly
-    # comparable with the HIP-event average reported below.
-    import math
-    per_launch = math.gcd(args.steps, args.warmup) if args.warmup > 0 else args.steps
-    # ... and no launch much longer than a second (config 3 at its full 65536 chains x 1e6 points
-    # takes 0.14 s per iteration): the largest divisor that keeps chains x points x iterations
-    # under 1e12
+    # The warm-up is ONE launch of `warmup` fused iterations and the timed region ONE launch of
+    # `steps` iterations (rocprofv3's kernel trace therefore shows two dispatches of the step
+    # kernel: profiles/ quotes the second).  Only a launch that would run for many seconds is
+    # cut: config 3 at its full 65536 chains x 1e6 points takes 0.14 s per iteration, so launches
+    # keep chains x points x iterations under 1e12.
     work = chains * float(sum(len(d[0]) for d in spec.data))
-    while per_launch > 1 and work * per_launch > 1e12:
-        per_launch = max(q for q in range(1, per_launch) if per_launch % q == 0)
-    for _ in range(args.warmup // per_launch if args.warmup > 0 else 0):
-        e.adaptive_advance(per_launch, count=False)
+
+    def launches_of(n):
+        per = n
+        while per > 1 and work * per > 1e12:
+            per = max(q for q in range(1, per) if per % q == 0)
+        return per, (n // per if per else 0)
+
+    w_per, w_n = launches_of(args.warmup) if args.warmup > 0 else (0, 0)
+    for _ in range(w_n):
+        e.adaptive_advance(w_per, count=False)
+    per_launch, n_launch = launches_of(args.steps)
     e.kernel_timing(reset=True)
     steps0 = e.counters()[0]
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps // per_launch):
+    for _ in range(n_launch):
         e.adaptive_advance(per_launch, count=False)  # one launch = per_launch fused iterations
     sync()
     t1 = time.perf_counter()
@@ -217,9 +261,48 @@ def main():
     assert (st != mhx.capi.CHAIN_FP_TRAP).all(), "a chain trapped during the benchmark"
     assert chain_steps == chains * args.steps, (chain_steps, chains, args.steps)
 
+    n_points = int(sum(len(d[0]) for d in spec.data))
     bytes_step = b_alg(spec, b_pt)
-    kernel_s = kt["total_ms"] * 1e-3
-    achieved = chain_steps * bytes_step / kernel_s / 1e9  # this rank's dominant kernel
+    kernel_s = kt["total_ms"] * 1e-3  # HIP events on the engine's stream around the launch(es)
+    alg_gbs = chain_steps * bytes_step / kernel_s / 1e9
+    # The roof that binds is fp64 VALU issue, not HBM: the chains of a workgroup share every data
+    # tile through LDS and the dataset sits in L2, so HBM traffic is a fraction of a per cent of
+    # the algorithmic bytes.  achieved = VALU wave-instructions per second x 128 (an fma: 2 flop x
+    # 64 lanes), with the instructions per data point MEASURED (SQ_INSTS_VALU of the timed launch
+    # of this same command, rocprofv3 --pmc, committed under profiles/); peak = 1024 SIMDs x
+    # 2.4 GHz / 4 cycles per wave64 fp64 instruction x 128 = 78.6 TFLOP/s.
+    prof, prof_name, prof_exact = load_profile(args.workload, args.steps, args.warmup) if world == 1 else (None, None, False)
+    roof = {"bound": "fp64_valu", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": None, "traffic": None,
+            "kernel_ms_per_launch": kt["avg_ms"], "launches": kt["launches"],
+            "iterations_per_launch": per_launch,
+            "algorithmic_bytes_per_chain_step": bytes_step, "algorithmic_gbs": alg_gbs,
+            "note": "fp64 VALU issue bound: 16 chains share each LDS tile and the dataset is L2 "
+                    "resident, so HBM (hbm_gbs, hbm_frac) does not bind; algorithmic_gbs = the "
+                    "SURVEY 8d bytes per chain-step x chain-steps / kernel time, for reference only"}
+    if prof is not None:
+        try:
+            pm, bs = prof["pmc_timed_launch"], prof["bench_stats"]
+            prof_points = (bs["roofline"]["iterations_per_launch"] * bs["config"]["chains_per_gpu"]
+                           * float(bs["config"]["n_points"]))
+            ipp = pm["SQ_INSTS_VALU"] * 64.0 / prof_points  # wave-instructions x 64 lanes / points
+            instr = ipp * chain_steps * n_points / 64.0     # wave-instructions of THIS timed region
+            roof["instr_per_point"] = ipp
+            roof["instr_source"] = ("profiles/%s: SQ_INSTS_VALU of the timed launch%s"
+                                    % (prof_name, "" if prof_exact else
+                                       " (NOT the same --steps/--warmup: the count per point depends "
+                                       "on where in the walk the launch sits)"))
+            roof["achieved"] = instr * 128.0 / kernel_s / 1e12
+            roof["frac"] = roof["achieved"] / FP64_VALU_PEAK_TFLOPS
+            prof_steps = bs["roofline"]["iterations_per_launch"] * bs["config"]["chains_per_gpu"]
+            hbm_per_step = (prof["hbm_read_bytes"] + prof["hbm_write_bytes"]) / prof_steps
+            # HBM bytes per launch: FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024
+            # of the profiled launch, scaled by chain-steps
+            roof["traffic"] = hbm_per_step * per_launch * chains
+            roof["hbm_gbs"] = hbm_per_step * chain_steps / kernel_s / 1e9
+            roof["hbm_frac"] = roof["hbm_gbs"] / HBM_PEAK_GBS
+        except Exception:  # a malformed summary must not break the benchmark
+            pass
     out = {
         "metric": "chain-steps/sec (whole node), 1e5-pt Gaussian log-lik, 8 params"
                   if args.workload == "c2" else "chain-steps/sec (whole node), workload %s" % args.workload,
@@ -234,42 +317,24 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": desc, "chains_per_gpu": chains, "n_points": int(sum(len(d[0]) for d in spec.data)),
+        "config": {"workload": desc, "chains_per_gpu": chains, "n_points": n_points,
                    "n_params": spec.d,
                    "adaptation": ("pooled covariance, all-reduce of %d doubles / 200 iterations" % (1 + spec.d + spec.d ** 2))
                    if pooled else "faithful per-walker (no collective)",
                    "parallelism": "chains sharded over %d GPU(s)" % world,
                    "kernel": "k_adaptive @ " + e.kernel_name()},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_chain_step": bytes_step,
-                     "kernel_ms_per_launch": kt["avg_ms"], "launches": kt["launches"],
-                     "iterations_per_launch": per_launch,
-                     "note": "dataset is L2/MALL resident and shared by the chains of a workgroup "
-                             "through LDS; the kernel is fp64-VALU bound (DESIGN.md)"},
+        "roofline": roof,
     }
-    # HBM traffic of this launch from the PMC passes committed under profiles/ (rocprofv3 cannot
-    # run inside this process): FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024,
-    # measured on the same command (200 iterations x 4096 chains), scaled by chain-steps
-    prof = os.path.join(ROOT, "profiles", "r01_%s_summary.json" % args.workload)
-    if os.path.exists(prof) and world == 1:
-        try:
-            ps = json.load(open(prof))
-            # the summary's counters belong to ONE launch (the last one of the profiled run)
-            bs = ps["bench_stats"]
-            prof_steps = (bs["roofline"].get("iterations_per_launch", bs["steps"])
-                          * bs["config"]["chains_per_gpu"])
-            per_step = (ps["hbm_read_bytes"] + ps["hbm_write_bytes"]) / prof_steps
-            out["roofline"]["traffic"] = per_step * per_launch * chains  # per launch, like `achieved`
-            out["roofline"]["algorithmic_bytes_per_launch"] = bytes_step * per_launch * chains
-            out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(prof)
-        except Exception:  # a malformed summary must not break the benchmark
-            pass
     if rank == 0 and world == 1 and not args.no_cpu:
-        v, n_s, t_s = cpu_baseline(spec, th0[0], args.cpu_seconds, n_adapt)
-        out["cpu_baseline"] = {"value": v, "unit": "chain-steps/s", "cores": 1, "kind": "port",
-                               "sample": "1 chain x %d steps of the same workload (%.1f s), "
-                                         "oracle/ faithful serial order, glibc libm" % (n_s, t_s)}
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        one = cpu_baseline(spec, th0, args.cpu_seconds * 0.4, n_adapt, 1, l0)
+        allc = cpu_baseline(spec, th0, args.cpu_seconds * 0.6, n_adapt, ncpu, l0) if ncpu > 1 else one
+        out["cpu_baseline"] = {
+            "value": allc[0], "unit": "chain-steps/s", "cores": ncpu, "kind": "port",
+            "sample": "%d chains (one per core) x %d steps in all of the same workload (%.1f s), "
+                      "oracle/ faithful serial order, glibc libm" % (ncpu, allc[1], allc[2]),
+            "single_core": {"value": one[0], "cores": 1,
+                            "sample": "1 chain x %d steps (%.1f s)" % (one[1], one[2])}}
     if rank == 0:
         print(json.dumps(out))
     e.close()

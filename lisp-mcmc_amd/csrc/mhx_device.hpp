@@ -41,9 +41,36 @@ constexpr int kThreads = kWave * kWavesPerGroup;
 constexpr int kTilePoints = tile_points_of(kWavesPerGroup);  // data points per LDS tile and array
 
 // ------------------------------------------------------------------------------------------
+// Every kernel's dynamic LDS starts with the two look-up tables of the device math (filled by
+// lds_tables_begin()): the kernels that stage data tiles put them in front of their GroupLds, the
+// split-mode sweep kernel allocates nothing else (kSweepLdsBytes).
+// ------------------------------------------------------------------------------------------
+struct LdsHead {
+  double logtab[256];      // kLogTab: {1/c_i, log c_i} of tlog()                      2 KiB
+  double exp2tab[256][2];  // kExp2Tab: {RN(2^(j/256)), its relative residual} of texp2   4 KiB
+};
+extern __shared__ __attribute__((aligned(16))) unsigned char mhx_lds_raw[];
+typedef __attribute__((address_space(3))) const double* lds_cdptr_t;
+typedef double mhx_double2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const mhx_double2* lds_cd2ptr_t;
+__device__ __forceinline__ lds_cdptr_t lds_logtab() {
+  return (lds_cdptr_t)reinterpret_cast<LdsHead*>(mhx_lds_raw)->logtab;
+}
+__device__ __forceinline__ lds_cd2ptr_t lds_exp2tab() {
+  return (lds_cd2ptr_t)reinterpret_cast<LdsHead*>(mhx_lds_raw)->exp2tab;
+}
+
+// ------------------------------------------------------------------------------------------
 // wave helpers
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// (opaque to the optimiser: every use site forms its lane number, and what it derives from it,
+// afresh - one v_and_b32 - instead of keeping per-lane offsets and addresses of the cold
+// controller code alive, i.e. in scratch, across the likelihood sweep)
+__device__ __forceinline__ int lane_id() {
+  int l = threadIdx.x & 63;
+  asm volatile("" : "+v"(l));
+  return l;
+}
 __device__ __forceinline__ int wave_in_group() {
   return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 }
@@ -205,55 +232,122 @@ __device__ __forceinline__ double mexp2(double s) {
   p = __builtin_fma(p, f, 1.0);
   return ldexp(p, (int)kf);
 }
-// 2^(-t*t): the same, with the exponent formed inside the two fmas (k = rint(-t^2) and
-// f = -t^2 - k each with ONE rounding: one instruction fewer and a more accurate f than
-// squaring first).  15 VALU instructions.
-// Valid for |t| < 46340 (t^2 < 2^31): then k is the low dword of kd, no conversion needed.
-// Callers establish the bound once per step from the dataset's x range (Prep::fast).
-// 14 VALU instructions.
-// c11 = kExp2C11, handed in from a VGPR the caller keeps alive across its loop: the first
-// Horner step reads two constants, and only one may come from the scalar file
-constexpr double kExp2C11 = 0x1.e9d3fe3952179p-32;
-// The constants of mexp2_negsq, pinned to register files once per step by the caller: every
-// v_fma_f64 of the Horner chain may read ONE scalar operand, so c[0..9] and the magic number
-// live in SGPRs and c11 (which shares the first fma with c[0]) in a VGPR.  Left to itself the
-// compiler materialises the coefficients in VGPRs as soon as the loop body has branches and
-// then copies one into the accumulator before every v_fmac - twice the instructions.
+// 2^(-t*t), table driven: s = -t^2 = k + j/256 + r with |r| <= 2^-9, all three parts from TWO
+// fmas (kd = fma(-t, t, 1.5 2^44) rounds s to a multiple of 1/256 - its low dword IS
+// 256 k + j, no conversion - and r = fma(-t, t, -(kd - 1.5 2^44)) is exact to one rounding);
+// 2^s = 2^k Th_j (1 + rho_j) 2^r with {Th_j, rho_j} = {RN(2^(j/256)), what that rounding lost}
+// read from LDS by ONE ds_read_b128, 2^r - 1 = r q(r), q of degree 3 (tools/gen_exp2_table.py:
+// 4.8e-18 relative), e = fma(r, q, rho), p = fma(Th, e, Th), v_ldexp_f64.  12 VALU instructions
+// and one LDS read where the degree-11 polynomial took 15; <= 0.51 ulp (the table entry is exact
+// to 2^-105 through rho, so the final fma's rounding is the error): tests/test_device_math_cpu.py.
+// Valid for t^2 < 2^23 (|t| < 2896: then 256 s fits the low dword); callers establish
+// |t| < kFastT once per step from the dataset's x range (Prep::fast).
+// NaN propagates (the masked index keeps the table read in range).
+constexpr double kFastT = 2890.0;
+__device__ const double kExp2Tab[256][2] = {
+#include "mhx_exp2_table.inc"
+};
+// The constants, pinned to register files once per step by the caller: every v_fma_f64 may read
+// ONE scalar operand, so q2..q0 and the magic number live in SGPRs and q3 (which shares the
+// first fma with q2) in a VGPR.  Left to itself the compiler materialises the coefficients in
+// VGPRs as soon as the loop body has branches and copies one into the accumulator before every
+// v_fmac.
 struct Exp2K {
-  double c11;    // VGPR
-  double c[10];  // SGPRs: the coefficients of f^10 ... f^1
+  double q3;     // VGPR
+  double q[3];   // SGPRs: q2, q1, q0
   double magic;  // SGPR
   __device__ __forceinline__ void pin() {
-    constexpr double k[10] = {0x1.e6063f7217bc6p-28, 0x1.b524fae627834p-24, 0x1.62bfd47773353p-20,
-                              0x1.ffcbfc670dcd4p-17, 0x1.430913096fd9fp-13, 0x1.5d87fe78a5276p-10,
-                              0x1.3b2ab6fba1ddap-7,  0x1.c6b08d704a0c2p-5,  0x1.ebfbdff82c598p-3,
-                              0x1.62e42fefa39efp-1};
-    double v = kExp2C11;
+    constexpr double k[3] = {0x1.c6b0902b5a0abp-5, 0x1.ebfbdff82c585p-3, 0x1.62e42fefa39d9p-1};
+    double v = 0x1.3b2ab83eadfb0p-7;
     asm volatile("" : "+v"(v));
-    c11 = v;
+    q3 = v;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      double s = k[i];
-      asm volatile("" : "+s"(s));
-      c[i] = s;
+    for (int i = 0; i < 3; ++i) {
+      double c = k[i];
+      asm volatile("" : "+s"(c));
+      q[i] = c;
     }
-    double m = 0x1.8p52;
+    double m = 0x1.8p44;
     asm volatile("" : "+s"(m));
     magic = m;
   }
 };
-__device__ __forceinline__ double mexp2_negsq(double t, const Exp2K& K) {
+// In two halves, so that a caller with several independent arguments can issue all the table
+// reads before the first polynomial (an LDS read takes ~64+ cycles to come back; left to the
+// compiler every exp waits for its own):  head = reduction + the read, tail = the rest.
+struct Exp2Head {
+  double r;       // |r| <= 2^-9
+  int lo;         // 256 k + j
+  mhx_double2 e;  // {Th_j, rho_j}, in flight until the tail uses it
+};
+__device__ __forceinline__ void mexp2_negsq_head(double t, const Exp2K& K, Exp2Head& h) {
   const double kd = __builtin_fma(-t, t, K.magic);
   const double kf = kd - K.magic;
-  const double f = __builtin_fma(-t, t, -kf);
-  double p = K.c11;
+  h.r = __builtin_fma(-t, t, -kf);
+  h.lo = (int)__double_as_longlong(kd);
+  h.e = lds_exp2tab()[h.lo & 255];
+}
+__device__ __forceinline__ double mexp2_negsq_tail(const Exp2Head& h, const Exp2K& K) {
+  double a = __builtin_fma(h.r, K.q3, K.q[0]);
+  a = __builtin_fma(h.r, a, K.q[1]);
+  a = __builtin_fma(h.r, a, K.q[2]);
+  const double ee = __builtin_fma(h.r, a, h.e.y);
+  return ldexp(__builtin_fma(h.e.x, ee, h.e.x), h.lo >> 8);
+}
+__device__ __forceinline__ double mexp2_negsq(double t, const Exp2K& K) {
+  Exp2Head h;
+  mexp2_negsq_head(t, K, h);
+  return mexp2_negsq_tail(h, K);
+}
+// N independent arguments at once, STAGE BY STAGE (on[i] false: argument i is skipped, v[i]
+// untouched): all table reads are issued first, then every stage of the tail runs across the N
+// chains before the next stage starts.  A dependent v_fma_f64 can issue only every 8 cycles, an
+// independent one every 4 (tools/microbench/fma_chain): with the stages pinned by
+// sched_barriers a wave issues back to back whatever the other waves of its SIMD do.  Each
+// chain's operations are mexp2_negsq()'s: identical bits.
+template <int N>
+__device__ __forceinline__ void mexp2_negsq_batch(const double (&t)[N], const bool (&on)[N],
+                                                  const Exp2K& K, double (&v)[N]) {
+  Exp2Head h[N];
+  double a[N];
 #pragma unroll
-  for (int i = 0; i < 10; ++i) p = __builtin_fma(p, f, K.c[i]);
-  p = __builtin_fma(p, f, 1.0);
-  return ldexp(p, (int)__double_as_longlong(kd));  // low dword of 1.5*2^52 + k is k
+  for (int i = 0; i < N; ++i)
+    if (on[i]) mexp2_negsq_head(t[i], K, h[i]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (on[i]) a[i] = __builtin_fma(h[i].r, K.q3, K.q[0]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (on[i]) a[i] = __builtin_fma(h[i].r, a[i], K.q[1]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (on[i]) a[i] = __builtin_fma(h[i].r, a[i], K.q[2]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (on[i]) a[i] = __builtin_fma(h[i].r, a[i], h[i].e.y);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (on[i]) a[i] = __builtin_fma(h[i].e.x, a[i], h[i].e.x);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (on[i]) v[i] = ldexp(a[i], h[i].lo >> 8);
+}
+// t = x iw + c with iw in a scalar register and c in a vector register: ONE v_fma_f64.  (Written
+// as __builtin_fma the compiler sometimes picks the two-address v_fmac_f64 and copies c into
+// the destination first - an extra instruction per point and peak.)
+__device__ __forceinline__ double fma_svv(double x, double iw_s, double c_v) {
+  double t;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(t) : "s"(iw_s), "v"(x), "v"(c_v));
+  return t;
 }
 // any t (NaN propagates; |t| huge or inf gives 0): the guarded form for the rare step whose
-// parameters put |t| beyond 46340 somewhere in the data range
+// parameters put |t| beyond kFastT somewhere in the data range
 __device__ __forceinline__ double mexp2_negsq_safe(double t) {
   double s = -(t * t);
   s = s < -1100.0 ? -1100.0 : s;
@@ -436,7 +530,6 @@ __device__ const double kLogTab[128][2] = {
     {0x1.77908115fd694p-1, 0x1.3d54fa662a800p-2},
     {0x1.756cac1d7dd05p-1, 0x1.432ef2a76f800p-2},
 };
-typedef __attribute__((address_space(3))) const double* lds_cdptr_t;
 // a3: the constant 1/5 of the polynomial handed in from a VGPR the caller keeps alive across its
 // loop (tlog_a3()): fma(r, A4, A3) reads two constants and only one may come from the scalar
 // file - otherwise the compiler copies one into the accumulator before a v_fmac, every call
@@ -547,15 +640,16 @@ struct PeaksModel {
     double cv[NPK];  // mu[] once more, pinned in VGPRs: t = fma(x, iw, c) may read only ONE
                      // scalar operand (constant bus), so c would be re-copied for every point
     Exp2K K;         // the constants of the 2^f polynomial, pinned likewise
-    bool fast;  // |t| < 46000 over the whole x range for every peak (uniform)
+    bool fast;  // |t| < kFastT over the whole x range for every peak (uniform)
     bool skip;  // tile-level skipping allowed this step (see tile_mask)
     int thr[NPK];  // -(binary exponent of A_k) - 56
   };
   // Tile-level skipping of Gaussian peaks, an EXACT transformation of the fast path.
   // Over a tile whose x lie in [xlo, xhi], t_k = fma(x, iw_k, c_k) is monotone in x, so
   // |t_k| >= tmin = min(|t_k(xlo)|, |t_k(xhi)|) when both ends have the same sign, hence
-  // k = rint(-t^2) <= kmin = rint(-tmin^2) (the same fma, monotone) and the peak's value
-  // e = ldexp(p, k) with p < 2 obeys e < 2^(kmin+1).  With 0 <= A_k < 2^ea that bounds the
+  // k = floor(rint(-256 t^2) / 256) <= kmin, the same from tmin (the same fma; rounding and the
+  // arithmetic shift are monotone) and the peak's value e = ldexp(p, k) with
+  // p = Th (1 + e') < 2^(255/256 + 1/512) (1 + 2^-52) < 2 obeys e < 2^(kmin+1).  With 0 <= A_k < 2^ea that bounds the
   // addend of f = fma(A_k, e, f) by 2^(ea+kmin+1).  The running f is >= the background over the
   // tile, bmin = min(bg(xlo), bg(xhi)) (Horner fma, monotone for NBG <= 2; every earlier peak
   // added a non-negative amount), and bmin >= 2^(ef-1).  A double g > 0 has no neighbour closer
@@ -585,7 +679,7 @@ struct PeaksModel {
       const double al = fabs(tl), ah = fabs(th);
       const double tmin = al < ah ? al : ah;
       const double kd = __builtin_fma(-tmin, tmin, p.K.magic);
-      const int kmin = (int)__double_as_longlong(kd);  // |t| < 46000 on the fast path
+      const int kmin = (int)__double_as_longlong(kd) >> 8;  // (|t| < kFastT on the fast path)
       const bool noop = same_side && (kmin <= ef + p.thr[k]);
       m |= noop ? 0u : (1u << k);
     }
@@ -614,12 +708,12 @@ struct PeaksModel {
       p.iw[k] = uniform_f64(iw);
       p.mu[k] = uniform_f64(-mu * iw);  // additive constant of the fma below
       double cvk = p.mu[k];
-      asm volatile("" : "+v"(cvk));
+      if (NPK <= 2) asm volatile("" : "+v"(cvk));  // (more peaks: eval_n moves it per block)
       p.cv[k] = cvk;
       // t is linear in x: its extremes sit at the ends of the data range (NaN fails the test)
       const double ta = fabs(__builtin_fma(fn.xmin, p.iw[k], p.mu[k]));
       const double tb = fabs(__builtin_fma(fn.xmax, p.iw[k], p.mu[k]));
-      fast = fast && (ta < 46000.0) && (tb < 46000.0);
+      fast = fast && (ta < kFastT) && (tb < kFastT);
       // |A_k| < 2^ea; a negative, infinite or NaN amplitude switches skipping off
       skip = skip && (p.A[k] >= 0.0) && finite_f64(p.A[k]);
       p.thr[k] = __builtin_amdgcn_readfirstlane(-__builtin_amdgcn_frexp_exp(p.A[k]) - 56);
@@ -666,16 +760,52 @@ struct PeaksModel {
         for (int j = NBG - 2; j >= 0; --j) f[i] = __builtin_fma(f[i], x[i], p.bg[j]);
       }
     }
+    if constexpr (FAST && !LORENTZ && NPK * P <= 4) {
+      // (compile-time masks, <= 2 peaks x 2 points) all chains of the iteration as one batch
+      double t[NPK * P], v[NPK * P];
+      bool on[NPK * P];
+#pragma unroll
+      for (int k = 0; k < NPK; ++k)
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+          on[k * P + i] = !kHasSkip || ((mask >> k) & 1u);
+          t[k * P + i] = on[k * P + i] ? fma_svv(x[i], p.iw[k], p.cv[k]) : 0.0;
+        }
+      mexp2_negsq_batch<NPK * P>(t, on, p.K, v);
+#pragma unroll
+      for (int k = 0; k < NPK; ++k)
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+          if (on[k * P + i]) f[i] = __builtin_fma(p.A[k], v[k * P + i], f[i]);
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < NPK; ++k) {
       if (FAST && kHasSkip && !((mask >> k) & 1u)) continue;
+      if constexpr (FAST && !LORENTZ) {
+        // one peak (a basic block of its own under a run-time mask): its P points as one batch.
+        // The additive constant moves to a vector register HERE (one v_mov per block and P
+        // points) rather than being pinned in one for the whole sweep: NPK register pairs less
+        double t[P], v[P], ck = p.mu[k];
+        asm volatile("" : "+v"(ck));
+        bool on[P];
 #pragma unroll
-      for (int i = 0; i < P; ++i) {
-        const double t = __builtin_fma(x[i], p.iw[k], p.cv[k]);
-        if (LORENTZ)
-          f[i] = __builtin_fma(p.A[k], frcp(__builtin_fma(t, t, 1.0)), f[i]);
-        else
-          f[i] = __builtin_fma(p.A[k], FAST ? mexp2_negsq(t, p.K) : mexp2_negsq_safe(t), f[i]);
+        for (int i = 0; i < P; ++i) {
+          on[i] = true;
+          t[i] = fma_svv(x[i], p.iw[k], ck);
+        }
+        mexp2_negsq_batch<P>(t, on, p.K, v);
+#pragma unroll
+        for (int i = 0; i < P; ++i) f[i] = __builtin_fma(p.A[k], v[i], f[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+          const double t = __builtin_fma(x[i], p.iw[k], p.cv[k]);
+          if (LORENTZ)
+            f[i] = __builtin_fma(p.A[k], frcp(__builtin_fma(t, t, 1.0)), f[i]);
+          else
+            f[i] = __builtin_fma(p.A[k], mexp2_negsq_safe(t), f[i]);
+        }
       }
     }
   }
@@ -764,11 +894,17 @@ template <class M>
 struct model_peaks<M, decltype((void)M::kPeaks, void())> {
   static constexpr int value = M::kPeaks;
 };
+template <class M, class = void>
+struct model_has_eval_n { static constexpr bool value = false; };
+template <class M>
+struct model_has_eval_n<M, decltype((void)M::kHasEvalN, void())> {
+  static constexpr bool value = M::kHasEvalN;
+};
 // P points of one lane at once (models without an eval_n of their own: point after point)
 template <class M, bool FAST, int P>
 __device__ __forceinline__ void model_eval_n(const typename M::Prep& p, const double (&x)[P],
                                              unsigned mask, double (&f)[P]) {
-  if constexpr (model_has_skip<M>::value) {
+  if constexpr (model_has_skip<M>::value || model_has_eval_n<M>::value) {
     M::template eval_n<FAST, P>(p, x, mask, f);
   } else {
 #pragma unroll
@@ -870,7 +1006,7 @@ struct SinusoidModel {
 struct PVoigt2Model {
   // per peak: u = x*iw + c (c = -mu*iw); Lorentzian eta/(1+u^2) by frcp; Gaussian
   // (1-eta) exp(-u^2) = (1-eta) 2^(-t^2), t = x*(iw g) + c g, g = sqrt(log2 e).  Fast path (the
-  // low-dword exponent trick of mexp2_negsq) when |t| < 46000 over the dataset's x range.
+  // low-dword exponent trick of mexp2_negsq) when |t| < kFastT over the dataset's x range.
   static constexpr bool kHasFast = true;
   struct Prep {
     double A, b0, b1, c1, iw1, eta1, om1, c2p, iw2, eta2, om2, rho, c2;
@@ -894,11 +1030,20 @@ struct PVoigt2Model {
     p.g1c = a; p.g2c = b;
     const double e1 = fabs(__builtin_fma(fn.xmin, p.g1w, p.g1c)), e2 = fabs(__builtin_fma(fn.xmax, p.g1w, p.g1c));
     const double e3 = fabs(__builtin_fma(fn.xmin, p.g2w, p.g2c)), e4 = fabs(__builtin_fma(fn.xmax, p.g2w, p.g2c));
-    p.fast = (e1 < 46000.0) && (e2 < 46000.0) && (e3 < 46000.0) && (e4 < 46000.0);  // NaN fails
+    p.fast = (e1 < kFastT) && (e2 < kFastT) && (e3 < kFastT) && (e4 < kFastT);  // NaN fails
     p.K.pin();
     return p;
   }
   static __device__ __forceinline__ bool fast_ok(const Prep& p) { return p.fast; }
+  // everything but the two Gaussians
+  static __device__ __forceinline__ double finish(const Prep& p, double x, double u1, double u2,
+                                                  double g1, double g2) {
+    const double l1 = frcp(__builtin_fma(u1, u1, 1.0)), l2 = frcp(__builtin_fma(u2, u2, 1.0));
+    const double pv1 = __builtin_fma(p.eta1, l1, p.om1 * g1);
+    const double pv2 = __builtin_fma(p.eta2, l2, p.om2 * g2);
+    const double bg = __builtin_fma(p.c2, x * x, __builtin_fma(p.b1, x, p.b0));
+    return __builtin_fma(p.A, __builtin_fma(p.rho, pv2, pv1), bg);
+  }
   template <bool FAST>
   static __device__ __forceinline__ double eval(const Prep& p, double x) {
     const double u1 = __builtin_fma(x, p.iw1, p.c1), u2 = __builtin_fma(x, p.iw2, p.c2p);
@@ -910,11 +1055,33 @@ struct PVoigt2Model {
       g1 = mexp2_negsq_safe(u1 * kSqrtLog2e);
       g2 = mexp2_negsq_safe(u2 * kSqrtLog2e);
     }
-    const double l1 = frcp(__builtin_fma(u1, u1, 1.0)), l2 = frcp(__builtin_fma(u2, u2, 1.0));
-    const double pv1 = __builtin_fma(p.eta1, l1, p.om1 * g1);
-    const double pv2 = __builtin_fma(p.eta2, l2, p.om2 * g2);
-    const double bg = __builtin_fma(p.c2, x * x, __builtin_fma(p.b1, x, p.b0));
-    return __builtin_fma(p.A, __builtin_fma(p.rho, pv2, pv1), bg);
+    return finish(p, x, u1, u2, g1, g2);
+  }
+  // P points at once: the 2 P table reads of the Gaussians are issued before anything uses one
+  // (the Lorentzians' reciprocals fill the wait); per point the operations are eval()'s
+  static constexpr bool kHasEvalN = true;
+  template <bool FAST, int P>
+  static __device__ __forceinline__ void eval_n(const Prep& p, const double (&x)[P], unsigned,
+                                                double (&f)[P]) {
+    if constexpr (FAST) {
+      double t[2 * P], v[2 * P];
+      bool on[2 * P];
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        on[2 * i] = on[2 * i + 1] = true;
+        t[2 * i] = fma_svv(x[i], p.g1w, p.g1c);
+        t[2 * i + 1] = fma_svv(x[i], p.g2w, p.g2c);
+      }
+      mexp2_negsq_batch<2 * P>(t, on, p.K, v);
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        const double u1 = __builtin_fma(x[i], p.iw1, p.c1), u2 = __builtin_fma(x[i], p.iw2, p.c2p);
+        f[i] = finish(p, x[i], u1, u2, v[2 * i], v[2 * i + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < P; ++i) f[i] = eval<false>(p, x[i]);
+    }
   }
 };
 

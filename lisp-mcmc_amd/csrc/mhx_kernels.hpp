@@ -22,17 +22,29 @@ namespace mhx {
 inline namespace MHX_FAMILY {
 
 struct GroupLds {
+  // the tables of tlog() and mexp2_negsq(): 6 KiB.  FIRST member: the split-mode sweep kernel,
+  // which stages no tiles, allocates only this much dynamic LDS (kSweepLdsBytes), and the device
+  // math finds its tables at the same addresses in every kernel (mhx_device.hpp).
+  LdsHead head;
   double tiles[2][kMaxArrays][kTilePoints];        // 64 KiB
   double prop[kWavesPerGroup][MHX_MAX_PARAMS];     // proposal theta' of each wave, 4 KiB
   double prm[kWavesPerGroup][MHX_MAX_FN_PARAMS + 4];
-  double logtab[256];  // kLogTab, for tlog() in the Poisson sweep: 2 KiB
+  double park[kWavesPerGroup][12];  // a ChainPark per wave: the chain's scalars during a sweep
   int resident;  // 1: tile 0 of the problem's only function sits in tiles[0] (FnDesc::solo)
 };
+constexpr unsigned kSweepLdsBytes = sizeof(LdsHead);  // dynamic LDS of k_split_sweep
+static_assert(__builtin_offsetof(GroupLds, head) == 0, "the tables must lead the dynamic LDS");
 
 // every kernel that sweeps starts with this (LDS comes up uninitialised)
+__device__ __forceinline__ void lds_tables_begin() {
+  LdsHead& h = *reinterpret_cast<LdsHead*>(mhx_lds_raw);
+  const int t = threadIdx.x;  // (every workgroup has >= 256 threads... or loops)
+  for (int i = t; i < 256; i += blockDim.x) h.logtab[i] = kLogTab[i >> 1][i & 1];
+  for (int i = t; i < 512; i += blockDim.x) h.exp2tab[i >> 1][i & 1] = kExp2Tab[i >> 1][i & 1];
+}
 __device__ __forceinline__ void lds_begin(GroupLds& lds) {
   if (threadIdx.x == 0) lds.resident = 0;
-  if (threadIdx.x < 256) lds.logtab[threadIdx.x] = kLogTab[threadIdx.x >> 1][threadIdx.x & 1];
+  lds_tables_begin();
   __syncthreads();
 }
 
@@ -195,7 +207,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
                 acc = acc + ((kWhole || gi < f.n) ? tt : 0.0);
               } else {
                 // (- (* k (log lambda)) lambda ...) M:383; pads masked (no neutral pad exists)
-                const double tt = __builtin_fma(y[i], tlog(m[i], (lds_cdptr_t)lds.logtab, log_a3), -m[i]);
+                const double tt = __builtin_fma(y[i], tlog(m[i], lds_logtab(), log_a3), -m[i]);
                 acc = acc + ((kWhole || gi < f.n) ? tt : 0.0);
               }
             }
@@ -304,7 +316,8 @@ __device__ __forceinline__ double sweep_direct(const FnDesc& f, const typename M
       acc0 = acc0 + (i0 < f.n ? t0 : 0.0);
       acc1 = acc1 + (i1 < f.n ? t1 : 0.0);
     } else {
-      const double t0 = __builtin_fma(y0, mlog(m0), -m0), t1 = __builtin_fma(y1, mlog(m1), -m1);
+      const lds_cdptr_t tab = lds_logtab();
+      const double t0 = __builtin_fma(y0, tlog(m0, tab), -m0), t1 = __builtin_fma(y1, tlog(m1, tab), -m1);
       acc0 = acc0 + (i0 < f.n ? t0 : 0.0);
       acc1 = acc1 + (i1 < f.n ? t1 : 0.0);
     }
@@ -333,7 +346,8 @@ struct FixedSpec {
     if constexpr (model_has_fast<Model>::value) {
       // uniform over the WORKGROUP only if every wave takes the same branch: the barriers
       // inside sweep() are workgroup-wide, so the choice is voted
-      const bool fast = __syncthreads_and(!active || Model::fast_ok(prep)) != 0;
+      const bool fast = __builtin_amdgcn_readfirstlane(
+                            __syncthreads_and(!active || Model::fast_ok(prep))) != 0;
       if (fast) return finish_lik<LIK>(f, sweep<Model, LIK, true>(f, prep, active, lds));
     }
     return finish_lik<LIK>(f, sweep<Model, LIK, false>(f, prep, active, lds));
@@ -512,7 +526,9 @@ __device__ __forceinline__ void ring_acceptance(const Ring& r, int take, int* nu
     const double b = last ? 0.0 : r.prob[r.slot(s + 1)];
     runs += (last || bits_of(a) != bits_of(b)) ? 1 : 0;
   }
-  *num = wave_sum_i(runs);
+  // (every lane holds the same sum; said to the compiler, so that what is decided from it - and
+  // the chain's counters updated under those decisions - stays in scalar registers)
+  *num = __builtin_amdgcn_readfirstlane(wave_sum_i(runs));
   *den = t;
 }
 // rational acceptance num/den against the single-float literals of M:898, M:911, M:930-941
@@ -544,14 +560,17 @@ __device__ __forceinline__ bool ring_stable_probs(const Ring& r, int sts) {
     if (s >= t - 200 && v > late) late = v;
     if (v < mn) mn = v;
   }
-  early = wave_max(early);
-  late = wave_max(late);
-  mn = -wave_max(-mn);
+  early = uniform_f64(wave_max(early));
+  late = uniform_f64(wave_max(late));
+  mn = uniform_f64(-wave_max(-mn));
   const double spread = early - mn;
   return fabs(early - late) < 0.5 && 4.0 < spread && spread < 9.0;
 }
 
 enum { L_OK = 0, L_CAUGHT = 1, L_INVALID = 2, L_EMPTY = 3 };
+#ifndef MHX_LM_INLINE
+#define MHX_LM_INLINE __forceinline__
+#endif
 // With finite inputs an inf is an overflow trap and a NaN can only follow an earlier overflow
 // (inf - inf), so any non-finite result means floating-point-overflow was signalled first:
 // caught by the handler-case of M:891-894.  Only the explicit 0/0 of M:597 is invalid.
@@ -584,7 +603,9 @@ __device__ __forceinline__ int ring_forward_list(const Ring& r, int take, int* f
 // sqrt(max 0 .), upper triangle 0).  Returns L_OK / L_CAUGHT (x/0, overflow) / L_INVALID (0/0).
 __device__ __forceinline__ int cholesky_seq(const double* cov, double* Lout, int d) {
   int cst = L_OK;
-  for (int e = 0; e < d * d; ++e) Lout[e] = 0.0;
+  double zero = 0.0;  // (formed here: hoisted out of the stepping loop it would live - spilled -
+  asm volatile("" : "+v"(zero));  // across every likelihood sweep)
+  for (int e = 0; e < d * d; ++e) Lout[e] = zero;
   for (int i = 0; i < d && cst == L_OK; ++i)
     for (int k = 0; k <= i && cst == L_OK; ++k) {
       double tmp = 0.0;
@@ -608,7 +629,7 @@ __device__ __forceinline__ int cholesky_seq(const double* cov, double* Lout, int
   return cst;
 }
 
-__device__ __noinline__ int ring_l_matrix(const Ring& r, int take, int* fwd, double* cov,
+__device__ MHX_LM_INLINE int ring_l_matrix(const Ring& r, int take, int* fwd, double* cov,
                                           double* Lout, lds_dptr_t avg, int* n_forward) {
   const int l = lane_id(), d = r.d;
   const int nf = ring_forward_list(r, take, fwd);
@@ -673,8 +694,6 @@ __device__ __noinline__ int ring_l_matrix(const Ring& r, int take, int* fwd, dou
 // ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
-extern __shared__ __attribute__((aligned(16))) unsigned char mhx_lds_raw[];
-
 template <class Spec>
 __device__ __forceinline__ void k_init_body(const ProblemDesc* __restrict__ Pp, ChainState S);
 template <class Spec>
@@ -761,20 +780,61 @@ __device__ __forceinline__ void k_init_body(const ProblemDesc* __restrict__ Pp, 
   }
 }
 
-// per-wave registers of one chain
+// A wave-uniform pointer the optimiser must treat as new: used on the base pointers of the
+// stepping loop once per iteration, so that the per-lane addresses formed from them (base +
+// lane offset: 2 VGPRs each) are recomputed where they are used instead of being hoisted out of
+// the loop and kept alive - i.e. spilled to scratch - across the likelihood sweep.
+template <class T>
+__device__ __forceinline__ T* fresh_ptr(T* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+// per-wave registers of one chain: wave-uniform values only (SGPRs).  The position theta and the
+// most likely position stay in HBM (S.theta, S.best_theta: rewritten when a proposal is taken /
+// a new best is found) and the proposal in LDS, so that no per-lane value is alive across the
+// likelihood sweep - the sweep may have all 128 VGPRs and nothing of the chain goes to scratch.
 struct ChainRegs {
-  double th;      // theta_j in lane j
-  double best_th;
   double prob0, best_prob, T;
   int64_t nh, length, age, loop_i, reset_index;
   uint64_t draw;
   int shutting, status;
 };
+// the same, parked in the wave's LDS slot while the likelihood sweep runs (with the accept
+// uniform drawn for the outstanding proposal): 96 bytes, written by lane 0, read back by
+// every lane (one address: a broadcast) and returned to scalar registers
+struct ChainPark {
+  double prob0, best_prob, T, u;
+  int64_t nh, length, age, loop_i, reset_index;
+  uint64_t draw;
+  int shutting, status;
+};
+__device__ __forceinline__ void chain_park(ChainPark& slot, const ChainRegs& r, double u) {
+  if (lane_id() == 0) {
+    slot.prob0 = r.prob0; slot.best_prob = r.best_prob; slot.T = r.T; slot.u = u;
+    slot.nh = r.nh; slot.length = r.length; slot.age = r.age; slot.loop_i = r.loop_i;
+    slot.reset_index = r.reset_index; slot.draw = r.draw;
+    slot.shutting = r.shutting; slot.status = r.status;
+  }
+}
+__device__ __forceinline__ void chain_unpark(const ChainPark& slot, ChainRegs& r, double& u) {
+  r.prob0 = uniform_f64(slot.prob0);
+  r.best_prob = uniform_f64(slot.best_prob);
+  r.T = uniform_f64(slot.T);
+  u = uniform_f64(slot.u);
+  r.nh = uniform_i64(slot.nh);
+  r.length = uniform_i64(slot.length);
+  r.age = uniform_i64(slot.age);
+  r.loop_i = uniform_i64(slot.loop_i);
+  r.reset_index = uniform_i64(slot.reset_index);
+  r.draw = (uint64_t)uniform_i64((int64_t)slot.draw);
+  r.shutting = __builtin_amdgcn_readfirstlane(slot.shutting);
+  r.status = __builtin_amdgcn_readfirstlane(slot.status);
+}
 
 __device__ __forceinline__ void chain_load(const ChainState& S, int64_t c, int d, ChainRegs& r) {
   const int l = lane_id();
-  r.th = l < d ? S.theta[c * d + l] : 0.0;
-  r.best_th = l < d ? S.best_theta[c * d + l] : 0.0;
+  (void)l;
   r.prob0 = uniform_f64(S.prob[c]);
   r.best_prob = uniform_f64(S.best_prob[c]);
   r.T = uniform_f64(S.temperature[c]);
@@ -790,10 +850,7 @@ __device__ __forceinline__ void chain_load(const ChainState& S, int64_t c, int d
 __device__ __forceinline__ void chain_store(const ChainState& S, int64_t c, int d,
                                             const ChainRegs& r) {
   const int l = lane_id();
-  if (l < d) {
-    S.theta[c * d + l] = r.th;
-    S.best_theta[c * d + l] = r.best_th;
-  }
+  (void)d;
   if (l == 0) {
     S.prob[c] = r.prob0;
     S.best_prob[c] = r.best_prob;
@@ -822,19 +879,30 @@ __device__ __forceinline__ double propose(const double* L, int d, double zv, dou
   return mini + th;
 }
 
-// walker-modify :add-step M:549-555 on the ring
-__device__ __forceinline__ void add_step(const ChainState& S, int64_t c, int d, ChainRegs& r) {
+// walker-modify :add-step M:549-555 on the ring.  th: the step's position (lane j: theta_j),
+// which is also S.theta's content; taken: the step is a newly accepted proposal (only then can it
+// be a new most likely step, and only then does S.theta change)
+__device__ __forceinline__ void add_step(const ChainState& S, int64_t c, int d, ChainRegs& r,
+                                         double th, bool taken) {
   const int l = lane_id();
   const int64_t slot = r.nh & (int64_t)(S.R - 1);
-  if (l < d) S.hist_theta[(c * S.R + slot) * d + l] = r.th;
+  if (l < d) {
+    S.hist_theta[(c * S.R + slot) * d + l] = th;
+    if (taken) S.theta[c * d + l] = th;
+  }
   if (l == 0) S.hist_prob[c * S.R + slot] = r.prob0;
   r.nh++;
   r.length++;
   r.age++;
-  if (r.prob0 > r.best_prob) {
+  if (r.prob0 > r.best_prob) {  // (a repeated step has prob0 <= best_prob already)
     r.best_prob = r.prob0;
-    r.best_th = r.th;
+    if (l < d) S.best_theta[c * d + l] = th;
   }
+}
+// theta_j of chain c in lane j (0 beyond d)
+__device__ __forceinline__ double chain_theta(const ChainState& S, int64_t c, int d) {
+  const int l = lane_id();
+  return l < d ? S.theta[c * d + l] : 0.0;
 }
 
 // accept test of M:1091-1092; log u is evaluated only when the first clause fails in the
@@ -868,7 +936,7 @@ __device__ __forceinline__ void k_step_injected_body(
     chain_load(S, c, d, r);
     run = r.status != MHX_CHAIN_FP_TRAP;
     const double zv = l < d ? z[c * d + l] : 0.0;
-    thp = propose(Lin + (per_chain_l ? c * d * d : 0), d, zv, r.th);
+    thp = propose(Lin + (per_chain_l ? c * d * d : 0), d, zv, chain_theta(S, c, d));
     if (l < d) lds.prop[w][l] = thp;
   }
   double ll, lp;
@@ -881,11 +949,8 @@ __device__ __forceinline__ void k_step_injected_body(
     const double uu = uniform_f64(u[c]), TT = uniform_f64(T[c]);
     // here the caller's u stands for (random 1.0d0); log as the runtime's libm would
     acc = (prob1 > r.prob0) || ((prob1 - r.prob0) / TT > det_log(uu));
-    if (acc) {
-      r.th = thp;
-      r.prob0 = prob1;
-    }
-    add_step(S, c, d, r);
+    if (acc) r.prob0 = prob1;
+    add_step(S, c, d, r, acc ? (l < d ? lds.prop[w][l] : 0.0) : chain_theta(S, c, d), acc != 0);
   }
   if (accepted && l == 0) accepted[c] = (unsigned char)acc;
   if (l == 0 && r.status != MHX_CHAIN_FP_TRAP) atomicAdd(S.step_counter, 1ULL);
@@ -933,10 +998,26 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
   int* fwd = S.fwd_idx + (valid ? c : 0) * R.sts;
   double* covs = S.mat_tmp + (valid ? c : 0) * 2 * d * d;
   double* lnew = covs + d * d;
-  const double factor = (2.38 * 2.38) / (double)d;  // (/ (expt 2.38d0 2) num-params) M:890
   const int64_t age0 = valid ? r.age : 0;
 
   for (int64_t it = 0; SPLIT || it < max_iters; ++it) {
+    const int l = lane_id();  // (formed per iteration: see lane_id())
+    int d_it = P.d;  // likewise the parameter count: what the cold code derives from it (the
+    asm volatile("" : "+s"(d_it));  // reciprocal behind e / d ...) is formed where it is used
+    const int d = d_it;
+    ring.d = d;
+    Lc = fresh_ptr(Lc);
+    ring.prob = fresh_ptr(ring.prob);
+    ring.theta = fresh_ptr(ring.theta);
+    fwd = fresh_ptr(fwd);
+    covs = fresh_ptr(covs);
+    lnew = fresh_ptr(lnew);
+    S.hist_theta = fresh_ptr(S.hist_theta);
+    S.theta = fresh_ptr(S.theta);
+    S.best_theta = fresh_ptr(S.best_theta);
+    S.hist_prob = fresh_ptr(S.hist_prob);
+    S.L_pool = fresh_ptr(S.L_pool);
+    S.split_prop = fresh_ptr(S.split_prop);
     bool running = valid && r.status == MHX_CHAIN_RUNNING;
     double thp = 0.0, u = 1.0;
     bool resumed = false;
@@ -967,7 +1048,9 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     if constexpr (SPLIT) {
       if (valid && l == 0) S.split_pending[c] = 0;
     }
-    if (!__syncthreads_or(running ? 1 : 0)) break;
+    // (the vote is the same in every lane; as a scalar it keeps the loop's exit - and so every
+    // counter of the chain that lives across it - out of the vector registers)
+    if (!__builtin_amdgcn_readfirstlane(__syncthreads_or(running ? 1 : 0))) break;
     if (running) {
       if (!plain) {
         // M:905-917
@@ -993,7 +1076,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
       const double rv = rng_lane_value(S.seed, gchain, r.draw, d);
       r.draw++;
       u = readlane_f64(rv, 63);
-      thp = propose(Lc, d, rv, r.th);
+      thp = propose(Lc, d, rv, chain_theta(S, c, d));
       if (l < d) lds.prop[w][l] = thp;
     }
     if constexpr (SPLIT) {  // hand the proposal to the sweep launch and stop here
@@ -1009,20 +1092,32 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     }  // !resumed
     double ll, lp;
     double prob1;
+    // the chain's scalars wait in LDS while the sweep runs: nothing of the chain is alive across
+    // it in registers, so the sweep has the whole register file and nothing goes to scratch
+    static_assert(sizeof(ChainPark) <= sizeof(lds.park[0]), "ChainPark slot");
+    ChainPark& slot = *reinterpret_cast<ChainPark*>(lds.park[w]);
+    if constexpr (!SPLIT) chain_park(slot, r, u);
     if constexpr (SPLIT)
       prob1 = split_logpost<Spec>(P, S, c, running, lds, w, &ll, &lp);
     else
       prob1 = group_logpost<Spec>(P, running, lds, w, &ll, &lp);
+    if constexpr (!SPLIT) chain_unpark(slot, r, u);
+    // the butterfly leaves the same bits in every lane: scalar from here on, and with it the
+    // accept decision and every counter of the chain changed under it
+    prob1 = uniform_f64(prob1);
     if (!running) continue;
     if (!finite_f64(prob1)) {
       r.status = MHX_CHAIN_FP_TRAP;
       continue;
     }
-    if (mh_accept(prob1, r.prob0, r.T, u)) {
-      r.th = thp;
-      r.prob0 = prob1;
+    {
+      // the proposal is still in the wave's LDS slot (nothing of it was kept in registers
+      // across the sweep)
+      const bool take =
+          __builtin_amdgcn_readfirstlane((int)mh_accept(prob1, r.prob0, r.T, u)) != 0;
+      if (take) r.prob0 = prob1;
+      add_step(S, c, d, r, take ? (l < d ? lds.prop[w][l] : 0.0) : chain_theta(S, c, d), take);
     }
-    add_step(S, c, d, r);
     if (plain) {
       r.loop_i++;
       continue;
@@ -1061,6 +1156,11 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
             } else {
               st = ring_l_matrix(ring, (int)R.sts, fwd, covs, lnew, (lds_dptr_t)lds.prop[w], &nf);
             }
+            // (/ (expt 2.38d0 2) num-params) M:890, formed here rather than once per launch: a
+            // value kept for this cold block would sit in a vector register across every sweep
+            int dq = d;
+            asm volatile("" : "+s"(dq));
+            const double factor = (2.38 * 2.38) / (double)dq;
             if (st == L_OK) {
               for (int e = l; e < d * d; e += kWave) Lc[e] = factor * lnew[e];
             } else if (st == L_CAUGHT) {  // handler-case returns the CURRENT l-matrix, which
@@ -1095,6 +1195,10 @@ __device__ __forceinline__ void k_split_sweep_body(const ProblemDesc* __restrict
   const int w = wave_in_group(), l = lane_id(), d = P.d;
   const int64_t c = blockIdx.y;
   if (__builtin_amdgcn_readfirstlane(S.split_pending[c]) == 0) return;  // nothing to judge
+  // the tables of tlog() (Poisson terms, log() in user expressions) and mexp2_negsq(): this
+  // kernel's whole dynamic LDS (kSweepLdsBytes), at the offsets every other kernel keeps them
+  lds_tables_begin();
+  __syncthreads();
   const int slot = (int)blockIdx.x * kWavesPerGroup + w;
   if (l < d) sprop[w][l] = S.split_prop[c * d + l];
   const double* th = sprop[w];

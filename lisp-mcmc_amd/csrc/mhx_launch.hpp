@@ -31,6 +31,7 @@ struct Family {
   int threads;          // 64 * waves_per_group
   int tile_points;      // data points per LDS tile and array
   size_t lds_bytes;     // dynamic LDS of the stepping kernels
+  size_t sweep_lds_bytes;  // dynamic LDS of the split-mode sweep kernel (the math tables)
   hipError_t (*configure)();
   hipError_t (*logpost)(int spec, hipStream_t st, const ProblemDesc* P, const double* theta,
                         int64_t n, double* out, double* parts);

@@ -185,7 +185,7 @@ static std::string generate(const std::vector<UserExpr>& models,
     << (ocml ? "exp(a)" : "gexp(a)") << "; }\n"
     << "__device__ __forceinline__ double mhx_ux_log(double a) { return "
     << (ocml ? "(a > 0.0 ? log(a) : __builtin_nan(\"\"))"
-             : "tlog(a, (lds_cdptr_t)reinterpret_cast<GroupLds*>(mhx_lds_raw)->logtab)")
+             : "tlog(a, lds_logtab())")
     << "; }\n";
   // Divisions by expressions that do not depend on x (1/w, 1/tau ...) are loop invariant; with
   // reciprocal math the compiler forms the reciprocal once per step instead of dividing per
@@ -387,9 +387,9 @@ static int build_once(const std::vector<UserExpr>& models, const std::vector<Use
     }
   }
   const char* hdr_src[] = {kSrc_mhx_kernels_hpp, kSrc_mhx_device_hpp, kSrc_mhx_types_hpp,
-                           kSrc_mhx_h};
+                           kSrc_mhx_h, kSrc_mhx_exp2_table_inc};
   const char* hdr_name[] = {"mhx_kernels.hpp", "mhx_device.hpp", "mhx_types.hpp",
-                            "../../include/mhx.h"};
+                            "../../include/mhx.h", "mhx_exp2_table.inc"};
   // the same family defines the ahead-of-time build of this workgroup shape gets (Makefile)
   const std::string wpg = "-DMHX_WPG=" + std::to_string(fam.waves_per_group);
   const std::string famns = "-DMHX_FAMILY=w" + std::to_string(fam.waves_per_group);
@@ -417,7 +417,7 @@ static int build_once(const std::vector<UserExpr>& models, const std::vector<Use
   }
   if (!from_cache) {
     hiprtcProgram p = nullptr;
-    int rc = r.CreateProgram(&p, prog->source.c_str(), "mhx_user.hip", 4, hdr_src, hdr_name);
+    int rc = r.CreateProgram(&p, prog->source.c_str(), "mhx_user.hip", 5, hdr_src, hdr_name);
     if (rc != 0) {
       *err = std::string("hiprtcCreateProgram: ") + (r.GetErrorString ? r.GetErrorString(rc) : "?");
       return -1;
@@ -568,7 +568,8 @@ hipError_t rtc_launch_split_sweep(const UserProgram& p, hipStream_t st, const Pr
   ChainState s = S;
   void* args[] = {(void*)&P, (void*)&s};
   return hipModuleLaunchKernel(p.f_split_sweep, (unsigned)slices, (unsigned)S.n_chains, 1,
-                               (unsigned)p.fam->threads, 1, 1, 0, st, args, nullptr);
+                               (unsigned)p.fam->threads, 1, 1, (unsigned)p.fam->sweep_lds_bytes, st,
+                               args, nullptr);
 }
 hipError_t rtc_launch_split_step(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                                  const ChainState& S, const RunDesc& R, int mode, int plain) {

@@ -453,29 +453,32 @@ double orc_logpost(const orc_problem* p, const double* theta, double* parts) {
 /* The faithful functions above follow the reference (serial sums, libm, divisions).  The
  * mirror follows lisp-mcmc_amd/csrc for problems made of GAUSS_PEAKS functions with the
  * normal likelihood (BASELINE config 2's kernel): 1/sigma and y/sigma formed once, exp as
- * 2^(-t^2) with the exponent built inside two fmas and a degree-11 polynomial, lane-strided
+ * 2^(-t^2) with the exponent built inside two fmas, a 256-entry table and a cubic, lane-strided
  * accumulation (lane l of 64 takes points l, l+64, ...; two accumulators alternate) and the
  * xor butterfly.  fma() here is the C99 correctly rounded one, so the result is BIT-IDENTICAL
  * to the device's.  It exists to turn "within tolerance" into "equal" in the tests; the
  * tolerance between mirror and faithful is checked on the CPU. */
+/* csrc/mhx_device.hpp: mexp2_negsq.  s = -t^2 = k + j/256 + r from two fmas (the low dword of
+ * kd = fma(-t, t, 1.5 2^44) is 256 k + j), {Th_j, rho_j} from the table the device stages in LDS
+ * (the SAME generated file, tools/gen_exp2_table.py), 2^r - 1 = r q(r). */
+static const double mir_exp2_tab[256][2] = {
+#include "../lisp-mcmc_amd/csrc/mhx_exp2_table.inc"
+};
+#define MIR_FAST_T 2890.0 /* kFastT */
 static double mir_exp2_negsq(double t) {
-  const double MAGIC = 0x1.8p52;
+  const double MAGIC = 0x1.8p44;
+  const double q3 = 0x1.3b2ab83eadfb0p-7, q2 = 0x1.c6b0902b5a0abp-5, q1 = 0x1.ebfbdff82c585p-3,
+               q0 = 0x1.62e42fefa39d9p-1;
   double kd = fma(-t, t, MAGIC);
   double kf = kd - MAGIC;
-  double f = fma(-t, t, -kf);
-  double p = 0x1.e9d3fe3952179p-32;
-  p = fma(p, f, 0x1.e6063f7217bc6p-28);
-  p = fma(p, f, 0x1.b524fae627834p-24);
-  p = fma(p, f, 0x1.62bfd47773353p-20);
-  p = fma(p, f, 0x1.ffcbfc670dcd4p-17);
-  p = fma(p, f, 0x1.430913096fd9fp-13);
-  p = fma(p, f, 0x1.5d87fe78a5276p-10);
-  p = fma(p, f, 0x1.3b2ab6fba1ddap-7);
-  p = fma(p, f, 0x1.c6b08d704a0c2p-5);
-  p = fma(p, f, 0x1.ebfbdff82c598p-3);
-  p = fma(p, f, 0x1.62e42fefa39efp-1);
-  p = fma(p, f, 1.0);
-  return ldexp(p, (int)(int32_t)(uint32_t)to_bits(kd)); /* low dword of 1.5*2^52 + k is k */
+  double r = fma(-t, t, -kf);
+  int32_t lo = (int32_t)(uint32_t)to_bits(kd);
+  const double th = mir_exp2_tab[lo & 255][0], rho = mir_exp2_tab[lo & 255][1];
+  double a = fma(r, q3, q2);
+  a = fma(r, a, q1);
+  a = fma(r, a, q0);
+  double ee = fma(r, a, rho);
+  return ldexp(fma(th, ee, th), (int)(lo >> 8)); /* arithmetic shift, as v_ashrrev_i32 */
 }
 
 static double mir_dexp(double x) {
@@ -531,10 +534,10 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
     A[k] = local[nbg + 3 * k];
     iw[k] = ksl2e / local[nbg + 3 * k + 2];
     cc[k] = -local[nbg + 3 * k + 1] * iw[k];
-    /* the kernel's fast path (|t| < 46000 over the data range); anything else takes a
+    /* the kernel's fast path (|t| < kFastT over the data range); anything else takes a
      * differently rounded guarded path that is not mirrored */
     double ta = fabs(fma(xmin, iw[k], cc[k])), tb = fabs(fma(xmax, iw[k], cc[k]));
-    if (!(ta < 46000.0) || !(tb < 46000.0)) {
+    if (!(ta < MIR_FAST_T) || !(tb < MIR_FAST_T)) {
       *supported = 0;
       return NAN;
     }

@@ -141,3 +141,90 @@ def test_expression_exp_stays_below_one_ulp():
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, c, "-lm"])
     worst, ok = subprocess.check_output([exe]).decode().split()
     assert float(worst) < 1.0 and ok == "1", (worst, ok)
+
+
+# ---- mexp2_negsq: the table-driven 2^(-t^2) of the Gaussian peaks --------------------------------
+EXP2_INC = os.path.join(ROOT, "lisp-mcmc_amd", "csrc", "mhx_exp2_table.inc")
+
+
+def test_exp2_table_properties():
+    """Th_j = RN(2^(j/256)) and Th_j (1 + rho_j) = 2^(j/256) to far below an ulp; the constants in
+    the header are the ones tools/gen_exp2_table.py prints for N = 256, degree 4."""
+    mp = pytest.importorskip("mpmath")
+    mp.mp.prec = 300
+    rows = re.findall(r"\{(-?0x[0-9a-f.]+p[+-]\d+), (-?0x[0-9a-f.]+p[+-]\d+)\}", open(EXP2_INC).read())
+    assert len(rows) == 256
+    for j, (a, b) in enumerate(rows):
+        th, rho = float.fromhex(a), float.fromhex(b)
+        true = mp.power(2, mp.mpf(j) / 256)
+        assert th == float(true), j                                   # correctly rounded
+        assert abs(mp.mpf(th) * (1 + mp.mpf(rho)) / true - 1) < mp.mpf(2) ** -100, j
+        assert abs(rho) <= 2.0 ** -53
+    src = open(HDR).read()
+    out = subprocess.check_output(["python3", os.path.join(ROOT, "tools", "gen_exp2_table.py"), "256", "4"]).decode()
+    q = re.findall(r"q\d = (0x[0-9a-f.]+p[+-]\d+)", out)
+    assert len(q) == 4
+    for c in q:
+        assert c in src, c
+    err = float(re.search(r"2\^-9: ([0-9.e-]+)", out).group(1))
+    assert err < 1e-17  # the cubic's own error: 0.05 ulp
+
+
+EXP2_SRC = r'''
+#include <math.h>
+#include <quadmath.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+static const double T[256][2] = {
+#include "%s"
+};
+/* mexp2_negsq() of csrc/mhx_device.hpp with C99 fma */
+static double mexp2_negsq(double t) {
+  const double MAGIC = 0x1.8p44;
+  const double q3 = 0x1.3b2ab83eadfb0p-7, q2 = 0x1.c6b0902b5a0abp-5, q1 = 0x1.ebfbdff82c585p-3,
+               q0 = 0x1.62e42fefa39d9p-1;
+  double kd = fma(-t, t, MAGIC), kf = kd - MAGIC, r = fma(-t, t, -kf);
+  uint64_t b; memcpy(&b, &kd, 8);
+  int32_t lo = (int32_t)(uint32_t)b;
+  double a = fma(r, q3, q2); a = fma(r, a, q1); a = fma(r, a, q0);
+  double ee = fma(r, a, T[lo & 255][1]);
+  return ldexp(fma(T[lo & 255][0], ee, T[lo & 255][0]), lo >> 8);
+}
+int main(void) {
+  double maxu = 0, maxr = 0; srand48(7);
+  long bad = 0;
+  for (long n = 0; n < 3000000; ++n) {
+    double t; int m = n %% 4;
+    if (m == 0) t = (drand48() * 2 - 1) * 6.0;          /* the body of a peak */
+    else if (m == 1) t = (drand48() * 2 - 1) * 26.5;    /* down to 2^-700 */
+    else if (m == 2) t = (drand48() * 2 - 1) * 0.1;     /* the top */
+    else t = ldexp(drand48(), -(int)(drand48() * 60));  /* tiny arguments */
+    __float128 s = -(__float128)t * (__float128)t;      /* exact: 106 bits fit 113 */
+    __float128 ref = exp2q(s);
+    double got = mexp2_negsq(t);
+    double ulp = ldexp(1.0, ilogb((double)ref) - 52);
+    double u = (double)fabsq((__float128)got - ref) / ulp;
+    if (u > maxu) maxu = u;
+    double kd = fma(-t, t, 0x1.8p44), r = fma(-t, t, -(kd - 0x1.8p44));
+    if (fabs(r) > maxr) maxr = fabs(r);
+  }
+  /* edges: exact 1 at 0, underflow to 0 (gradually), NaN propagates, bound of the fast path */
+  int ok = mexp2_negsq(0.0) == 1.0 && mexp2_negsq(40.0) == 0.0 && mexp2_negsq(-2889.9) == 0.0
+           && isnan(mexp2_negsq(NAN)) && mexp2_negsq(32.5) > 0.0 && mexp2_negsq(32.5) < 0x1p-1022
+           && maxr <= 0x1p-9;
+  printf("%%.4f %%d\n", maxu, ok);
+  return 0;
+}
+'''
+
+
+def test_table_exp2_stays_near_half_an_ulp():
+    d = tempfile.mkdtemp()
+    c, exe = os.path.join(d, "e.c"), os.path.join(d, "e")
+    open(c, "w").write(EXP2_SRC % EXP2_INC)
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, c, "-lquadmath", "-lm"])
+    worst, ok = subprocess.check_output([exe]).decode().split()
+    # 0.5 ulp from the final fma's rounding + the cubic's 0.04 + the roundings inside e
+    assert float(worst) < 0.56 and ok == "1", (worst, ok)

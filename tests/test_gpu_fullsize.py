@@ -176,3 +176,232 @@ def test_c2_complete_default_run_4096_chains(mhx, c2):
     assert (s["age"] > 2000).all() and (s["age"] <= 30001).all()
     assert (s["age"] < 30001).any()
     e.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 3 at full size: 65536 chains, 16 params, log-poisson, 1e6 points (M:379-383
+# through M:402-416) and config 4: 4096 chains, 8 datasets x 12500 points sharing 32 params
+# (M:1067-1070).  Same plan as config 2: a sample against the faithful oracle, the rest through
+# size-independent properties.
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c3():
+    import bench
+    spec, chains, b_pt, desc = bench.synth_workload("c3")
+    assert chains == 65536 and len(spec.data[0][0]) == 1000000 and spec.d == 16
+    return spec
+
+
+@pytest.fixture(scope="module")
+def c4():
+    import bench
+    spec, chains, b_pt, desc = bench.synth_workload("c4")
+    assert chains == 4096 and spec.K == 8 and spec.d == 32
+    assert all(len(d[0]) == 12500 for d in spec.data)
+    return spec
+
+
+def _skip_and_noskip(mhx, spec, chains, **kw):
+    """(engine with tile-level peak skipping, engine without); read when the problem is finalised"""
+    out = []
+    for flag in ("0", "1"):
+        os.environ["MHX_NO_TILE_SKIP"] = flag
+        try:
+            e = spec.engine(mhx, chains, **kw)
+            e.kernel_name()  # finalises the problem under this setting
+        finally:
+            os.environ.pop("MHX_NO_TILE_SKIP", None)
+        out.append(e)
+    return out
+
+
+def test_c3_logpost_sample_vs_oracle_and_slot_independence(mhx, orc, c3):
+    op = c3.oracle(orc)
+    C_ = 65536
+    e = c3.engine(mhx, C_)
+    assert "gauss15_poisson" in e.kernel_name() and e.kernel_name().startswith("w16/")
+    th8 = pb.perturbed(c3.theta_star, 8, 0.01, seed=31)
+    got8, parts8 = e.logpost(th8, parts=True)
+    for c in range(8):
+        ref, pr = op.logpost(th8[c], parts=True)
+        tol = REL * op.abs_terms(th8[c])
+        assert abs(got8[c] - ref) <= tol, (c, got8[c], ref)
+        assert abs(parts8[c][0] - pr[0]) <= tol and parts8[c][1] == pr[1] == 0.0
+    # a vector outside its bounds box: the prior part carries the penalty (M:360)
+    out = th8[0].copy()
+    out[2] = c3.theta_star[2] * 1.7
+    g, gp = e.logpost(out[None, :], parts=True)
+    ref, pr = op.logpost(out, parts=True)
+    assert abs(gp[0][1] - pr[1]) <= 2.0 ** -52 * 1e10 and pr[1] < -1.0
+    assert abs(g[0] - ref) <= REL * op.abs_terms(out) + 2.0 ** -52 * 1e10
+    # the same 8 vectors in every one of the 65536 wave slots of ONE launch: same bits
+    got = e.logpost(np.tile(th8, (C_ // 8, 1)))
+    assert np.array_equal(got, np.tile(got8, C_ // 8))
+    e.close()
+
+
+def test_c3_additivity_and_permutation(mhx, orc, c3):
+    x, y, s, lik = c3.data[0]
+    th = pb.perturbed(c3.theta_star, 8, 0.01, seed=32)
+    e = c3.engine(mhx, 1)
+    whole = e.logpost(th)
+    e.close()
+    cut = 571392  # 279 tiles of 2048 points, then a ragged rest
+    sp = pb.Spec(16)
+    sp.add(pb.GAUSS, (1, 5), range(16), x[:cut], y[:cut], None, lik, c3.bounds[0])
+    sp.add(pb.GAUSS, (1, 5), range(16), x[cut:], y[cut:], None, lik, None)
+    e2 = sp.engine(mhx, 1)
+    split = e2.logpost(th)
+    e2.close()
+    perm = np.random.default_rng(33).permutation(x.size)
+    sq = pb.Spec(16)
+    sq.add(pb.GAUSS, (1, 5), range(16), x[perm], y[perm], None, lik, c3.bounds[0])
+    e3 = sq.engine(mhx, 1)
+    shuf = e3.logpost(th)
+    e3.close()
+    op = c3.oracle(orc)
+    for i in range(len(th)):
+        tol = REL * op.abs_terms(th[i])
+        assert abs(split[i] - whole[i]) <= tol
+        assert abs(shuf[i] - whole[i]) <= tol
+
+
+def test_c3_tile_skipping_is_exact_on_489_tiles(mhx, c3):
+    """1e6 points = 489 tiles of 2048: the 64-tile mask refresh of sweep() (lane i takes tile
+    t + i) runs 8 times per sweep for the Poisson kernel; with and without skipping the bits
+    must agree, for benign vectors, for narrow / wide / out-of-range peaks and on a walk"""
+    a, b = _skip_and_noskip(mhx, c3, 64, seed=5)
+    rng = np.random.default_rng(34)
+    th = pb.perturbed(c3.theta_star, 64, 0.01, seed=35)
+    for r in range(16, 64):
+        k = rng.integers(0, 5)
+        th[r, 2 + 3 * k] = rng.uniform(-0.2, 1.2)                 # centre, in and out of range
+        th[r, 3 + 3 * k] = 10.0 ** rng.uniform(-4.5, 0.3)         # width over 5 decades
+        th[r, 1 + 3 * k] = rng.choice([0.0, 1e-12, 3.0, 150.0, 1e6])  # amplitude
+        th[r, 0] = rng.choice([20.0, 1e-3, 5e4])
+    ga, gb = a.logpost(th), b.logpost(th)
+    assert np.array_equal(ga, gb) and np.isfinite(ga).all()
+    th0 = pb.perturbed(c3.theta_star, 64, 0.01, seed=36)
+    l0 = np.diag(0.002 * np.abs(c3.theta_star))
+    for e in (a, b):
+        e.init_chains(th0)
+        e.adaptive_begin(30000, 10.0, 1, l_matrix=l0)
+        e.adaptive_advance(6)
+    sa, sb = a.state(), b.state()
+    assert np.array_equal(sa["theta"], sb["theta"]) and np.array_equal(sa["logpost"], sb["logpost"])
+    assert (sa["age"] == 7).all()
+    a.close()
+    b.close()
+
+
+def test_c3_full_batch_walks_like_small_batch_and_oracle(mhx, orc, c3):
+    """20 iterations of walker-adaptive-steps on all 65536 chains x 1e6 points; chains of three
+    8-chain engines with the same global ids must coincide bit for bit, and chains 0..2 with the
+    oracle (positions equal, log-posteriors within the stated tolerance)"""
+    C_, n_it = 65536, 20
+    rng = np.random.Generator(np.random.Philox(key=0xC3))
+    th0 = c3.theta_star[None, :] * (1.0 + 0.01 * rng.standard_normal((C_, c3.d)))
+    l0 = np.diag(0.002 * np.abs(c3.theta_star))
+    big = c3.engine(mhx, C_, seed=13)
+    big.init_chains(th0)
+    big.adaptive_begin(30000, 10.0, 1, l_matrix=l0)
+    left = n_it
+    while left > 0:  # launches of <= 5 iterations (0.14 s each at this size)
+        assert big.adaptive_advance(min(left, 5)) == C_
+        left -= 5
+    sb = big.state()
+    assert (sb["age"] == n_it + 1).all() and big.counters()[0] == C_ * n_it
+    assert np.isfinite(sb["logpost"]).all()
+    st, _ = big.chain_status()
+    assert (st == mhx.capi.CHAIN_RUNNING).all()
+    assert (sb["theta"] != th0).any(axis=1).mean() > 0.5  # most chains have accepted something
+    for lo in (0, 30000, C_ - 8):
+        small = c3.engine(mhx, 8, seed=13, chain_offset=lo)
+        small.init_chains(th0[lo:lo + 8])
+        small.adaptive_begin(30000, 10.0, 1, l_matrix=l0)
+        small.adaptive_advance(n_it)
+        ss = small.state()
+        assert np.array_equal(sb["theta"][lo:lo + 8], ss["theta"]), lo
+        assert np.array_equal(sb["logpost"][lo:lo + 8], ss["logpost"]), lo
+        small.close()
+    op = c3.oracle(orc)
+    for c in range(3):
+        w = orc.Walker(op, th0[c])
+        w.adaptive_begin(30000, 10.0, 1, l_matrix=l0, seed=13, chain_id=c)
+        w.adaptive_advance(n_it)
+        th, pr = w.last()
+        assert np.array_equal(sb["theta"][c], th), c
+        assert abs(sb["logpost"][c] - pr) <= REL * op.abs_terms(th)
+        assert w.age == sb["age"][c]
+    big.close()
+
+
+def test_c4_logpost_sample_vs_oracle_slots_additivity_permutation(mhx, orc, c4):
+    op = c4.oracle(orc)
+    e = c4.engine(mhx, 4096)
+    assert "pvoigt2_normal" in e.kernel_name()
+    th8 = pb.perturbed(c4.theta_star, 8, 0.01, seed=41)
+    th8[7, 9] = 11.0  # outside (-10, 10): the bounds block is listed once per function, so the
+    #                   penalty is counted 8 times (M:1069)
+    got8, parts8 = e.logpost(th8, parts=True)
+    for c in range(8):
+        ref, pr = op.logpost(th8[c], parts=True)
+        slack = 8 * 2.0 ** -52 * 1e10 if c == 7 else 0.0
+        assert abs(got8[c] - ref) <= REL * op.abs_terms(th8[c]) + slack, c
+        assert abs(parts8[c][1] - pr[1]) <= slack
+    assert parts8[7][1] < -8.0 * 1e4
+    got = e.logpost(np.tile(th8, (512, 1)))
+    assert np.array_equal(got, np.tile(got8, 512))
+    e.close()
+    # every dataset cut in two (the functions of a 16-function global fit) and shuffled
+    sp, sq = pb.Spec(32), pb.Spec(32)
+    rng = np.random.default_rng(42)
+    halves = []
+    for k in range(8):
+        x, y, s, lik = c4.data[k]
+        model, shape, idx = c4.fns[k]
+        cut = 6144 + 512 * k
+        halves.append((model, shape, idx, x[cut:], y[cut:], s[cut:], lik))
+        sp.add(model, shape, idx, x[:cut], y[:cut], s[:cut], lik, c4.bounds[k])
+        p = rng.permutation(x.size)
+        sq.add(model, shape, idx, x[p], y[p], s[p], lik, c4.bounds[k])
+    for (model, shape, idx, x, y, s, lik) in halves:
+        sp.add(model, shape, idx, x, y, s, lik, None)
+    e2 = sp.engine(mhx, 1)
+    e3 = sq.engine(mhx, 1)
+    split, shuf = e2.logpost(th8[:7]), e3.logpost(th8[:7])
+    for i in range(7):
+        tol = REL * op.abs_terms(th8[i])
+        assert abs(split[i] - got8[i]) <= tol and abs(shuf[i] - got8[i]) <= tol
+    e2.close()
+    e3.close()
+
+
+def test_c4_full_batch_walks_like_small_batch_and_oracle(mhx, orc, c4):
+    C_, n_it = 4096, 40
+    rng = np.random.Generator(np.random.Philox(key=0xC4))
+    th0 = c4.theta_star[None, :] * (1.0 + 0.01 * rng.standard_normal((C_, c4.d)))
+    big = c4.engine(mhx, C_, seed=14)
+    big.init_chains(th0)
+    big.adaptive_begin(30000, 10.0, 1)
+    assert big.adaptive_advance(n_it) == C_
+    sb = big.state()
+    assert (sb["age"] == n_it + 1).all() and big.counters()[0] == C_ * n_it
+    for lo in (0, 2048, C_ - 8):
+        small = c4.engine(mhx, 8, seed=14, chain_offset=lo)
+        small.init_chains(th0[lo:lo + 8])
+        small.adaptive_begin(30000, 10.0, 1)
+        small.adaptive_advance(n_it)
+        ss = small.state()
+        assert np.array_equal(sb["theta"][lo:lo + 8], ss["theta"]), lo
+        assert np.array_equal(sb["logpost"][lo:lo + 8], ss["logpost"]), lo
+        small.close()
+    op = c4.oracle(orc)
+    for c in range(3):
+        w = orc.Walker(op, th0[c])
+        w.adaptive_begin(30000, 10.0, 1, seed=14, chain_id=c)
+        w.adaptive_advance(n_it)
+        th, pr = w.last()
+        assert np.array_equal(sb["theta"][c], th), c
+        assert abs(sb["logpost"][c] - pr) <= REL * op.abs_terms(th)
+    big.close()

@@ -212,3 +212,14 @@ def test_split_with_expression_likelihood(mhx):
         assert abs(st["logpost"][0] - ref) <= 1e-11 * float(np.sum(np.abs(y * np.log(m)) + m))
         assert abs(w.engine.logpost(th[None, :])[0] - st["logpost"][0]) <= 1e-11 * abs(ref)
     assert abs(b["theta"][0][2] - 0.4) < 0.02
+    # ... and the split chain must really have WALKED: with a wrong split-mode log-posterior
+    # (e.g. log() of the expression reading a table the sweep kernel never staged) every
+    # proposal is rejected, the stored log-posterior stays k_init's and all of the above holds
+    start = np.array(params[1::2])
+    for st, w in ((a, ws[0]), (b, ws[1])):
+        assert not np.array_equal(st["theta"][0], start)
+        acc = w.engine.acceptance(1000)[0]
+        assert 0.05 < acc < 0.7, acc
+        assert st["best_logpost"][0] > w.engine.logpost(start[None, :])[0]
+    # (the stored log-posterior of a chain that moved is the split sweep's value at an accepted
+    # proposal, so the comparison with mhx_logpost above is a comparison of the two sweeps)
