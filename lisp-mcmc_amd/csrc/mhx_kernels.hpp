@@ -86,10 +86,13 @@ struct CMask {
 };
 
 // Sum over the points of function f.  Collective over the workgroup (barriers inside);
-// waves with active == false only help to move tiles.
-template <class Model, int LIK, bool FAST = false>
+// waves with active == false only help to move tiles.  fast (wave-uniform): this chain's
+// parameters satisfy the model's fast-path precondition (model_has_fast) - decided per WAVE:
+// the tile pipeline and its barriers are common to both paths, only the arithmetic of the
+// wave's own points differs, so a chain's bits never depend on which chains share its workgroup.
+template <class Model, int LIK>
 __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::Prep& prep,
-                                        bool active, GroupLds& lds) {
+                                        bool active, GroupLds& lds, bool fast = false) {
   constexpr int NARR = LIK == MHX_LIK_POISSON ? 2 : (LIK == MHX_LIK_NORMAL_CUTOFF ? 4 : 3);
   static_assert(kTilePoints == 2 * kThreads, "one double2 per thread per array per tile");
   const int l = lane_id();
@@ -119,7 +122,8 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
     const int buf = (int)(t & 1);
     // buffer buf^1 was last read in iteration t-1, which every wave left through the barrier
     if (t + 1 < nt) tile_dma<NARR>(f, t + 1, lds, buf ^ 1, w);
-    if (active) {
+    auto tile_work = [&](auto fastc) {
+      constexpr bool FAST = decltype(fastc)::value;
       const double* tx = lds.tiles[buf][0];
       const double* ty = lds.tiles[buf][1];
       const double* tw = lds.tiles[buf][2];
@@ -233,27 +237,40 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
       };
       // Gaussian peaks that cannot change any sum of this tile by even one bit are left out
       // (PeaksModel::tile_mask; exact, so the results do not depend on it)
-      if constexpr (FAST && model_has_skip<Model>::value) {
-        // the masks of 64 consecutive tiles are worked out at once, lane i taking tile t + i
-        if ((t & 63) == 0) {
-          const int64_t ti = t + l < nt ? t + l : nt - 1;
-          tile_masks = Model::tile_mask(prep, f.txlo[ti], f.txhi[ti]);
-        }
-        const unsigned tm = (unsigned)__builtin_amdgcn_readlane((int)tile_masks, (int)(t & 63));
-        if constexpr (Model::kPeaks == 1) {
-          if (tm & 1u) tile_body(CMask<1u>{}); else tile_body(CMask<0u>{});
-        } else if constexpr (Model::kPeaks == 2) {
-          switch (tm & 3u) {
-            case 0u: tile_body(CMask<0u>{}); break;
-            case 1u: tile_body(CMask<1u>{}); break;
-            case 2u: tile_body(CMask<2u>{}); break;
-            default: tile_body(CMask<3u>{}); break;
+      // (the model test first, on its own: inside this generic lambda only a condition that does
+      // not depend on FAST keeps the skipping code from being checked against other models)
+      if constexpr (model_has_skip<Model>::value) {
+        if constexpr (FAST) {
+          // the masks of 64 consecutive tiles are worked out at once, lane i taking tile t + i
+          if ((t & 63) == 0) {
+            const int64_t ti = t + l < nt ? t + l : nt - 1;
+            tile_masks = Model::tile_mask(prep, f.txlo[ti], f.txhi[ti]);
+          }
+          const unsigned tm = (unsigned)__builtin_amdgcn_readlane((int)tile_masks, (int)(t & 63));
+          if constexpr (Model::kPeaks == 1) {
+            if (tm & 1u) tile_body(CMask<1u>{}); else tile_body(CMask<0u>{});
+          } else if constexpr (Model::kPeaks == 2) {
+            switch (tm & 3u) {
+              case 0u: tile_body(CMask<0u>{}); break;
+              case 1u: tile_body(CMask<1u>{}); break;
+              case 2u: tile_body(CMask<2u>{}); break;
+              default: tile_body(CMask<3u>{}); break;
+            }
+          } else {
+            tile_body(tm);  // more peaks: wave-uniform branches around each peak
           }
         } else {
-          tile_body(tm);  // more peaks: wave-uniform branches around each peak
+          tile_body(CMask<~0u>{});
         }
       } else {
         tile_body(CMask<~0u>{});
+      }
+    };
+    if (active) {
+      if constexpr (model_has_fast<Model>::value) {
+        if (fast) tile_work(BoolC<true>{}); else tile_work(BoolC<false>{});
+      } else {
+        tile_work(BoolC<false>{});
       }
     }
     if (!solo) {  // (a resident tile is never overwritten: nothing to wait for)
@@ -343,14 +360,10 @@ struct FixedSpec {
   static __device__ __forceinline__ double loglik(const FnDesc& f, PF pf, bool active,
                                                   GroupLds& lds, double*) {
     typename Model::Prep prep = Model::prepare(pf, f);
-    if constexpr (model_has_fast<Model>::value) {
-      // uniform over the WORKGROUP only if every wave takes the same branch: the barriers
-      // inside sweep() are workgroup-wide, so the choice is voted
-      const bool fast = __builtin_amdgcn_readfirstlane(
-                            __syncthreads_and(!active || Model::fast_ok(prep))) != 0;
-      if (fast) return finish_lik<LIK>(f, sweep<Model, LIK, true>(f, prep, active, lds));
-    }
-    return finish_lik<LIK>(f, sweep<Model, LIK, false>(f, prep, active, lds));
+    bool fast = false;
+    if constexpr (model_has_fast<Model>::value)
+      fast = __builtin_amdgcn_readfirstlane((int)Model::fast_ok(prep)) != 0;
+    return finish_lik<LIK>(f, sweep<Model, LIK>(f, prep, active, lds, fast));
   }
   static __device__ __forceinline__ double logprior(const FnDesc&, const double*, double bt) {
     return bt;

@@ -481,6 +481,31 @@ static double mir_exp2_negsq(double t) {
   return ldexp(fma(th, ee, th), (int)(lo >> 8)); /* arithmetic shift, as v_ashrrev_i32 */
 }
 
+/* csrc/mhx_device.hpp: mexp2_negsq_safe = mexp2(max(-(t t), -1100)), the guarded form a chain
+ * uses for a function whose parameters put |t| beyond kFastT somewhere in the data range */
+static double mir_exp2_negsq_safe(double t) {
+  const double MAGIC = 0x1.8p52;
+  double s = -(t * t);
+  s = s < -1100.0 ? -1100.0 : s;
+  const double kd = s + MAGIC;
+  const double kf = kd - MAGIC;
+  const double f = s - kf;
+  double p = 0x1.e9d3fe3952179p-32;
+  p = fma(p, f, 0x1.e6063f7217bc6p-28);
+  p = fma(p, f, 0x1.b524fae627834p-24);
+  p = fma(p, f, 0x1.62bfd47773353p-20);
+  p = fma(p, f, 0x1.ffcbfc670dcd4p-17);
+  p = fma(p, f, 0x1.430913096fd9fp-13);
+  p = fma(p, f, 0x1.5d87fe78a5276p-10);
+  p = fma(p, f, 0x1.3b2ab6fba1ddap-7);
+  p = fma(p, f, 0x1.c6b08d704a0c2p-5);
+  p = fma(p, f, 0x1.ebfbdff82c598p-3);
+  p = fma(p, f, 0x1.62e42fefa39efp-1);
+  p = fma(p, f, 1.0);
+  if (kf != kf) return kf; /* NaN in, NaN out (the device's v_cvt_i32_f64 of a NaN is 0) */
+  return ldexp(p, (int)kf);
+}
+
 static double mir_dexp(double x) {
   const double MAGIC = 0x1.8p52;
   double kd = fma(x, 1.4426950408889634074, MAGIC);
@@ -530,17 +555,16 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
     if (f->x[i] < xmin) xmin = f->x[i];
     if (f->x[i] > xmax) xmax = f->x[i];
   }
+  int fast = 1;
   for (int k = 0; k < npk; ++k) {
     A[k] = local[nbg + 3 * k];
     iw[k] = ksl2e / local[nbg + 3 * k + 2];
     cc[k] = -local[nbg + 3 * k + 1] * iw[k];
-    /* the kernel's fast path (|t| < kFastT over the data range); anything else takes a
-     * differently rounded guarded path that is not mirrored */
+    /* the kernel's fast path needs |t| < kFastT over the data range for EVERY peak of the
+     * function (PeaksModel::prepare); otherwise the chain evaluates all of them in the guarded
+     * form (the choice is the chain's own: csrc/mhx_kernels.hpp, sweep) */
     double ta = fabs(fma(xmin, iw[k], cc[k])), tb = fabs(fma(xmax, iw[k], cc[k]));
-    if (!(ta < MIR_FAST_T) || !(tb < MIR_FAST_T)) {
-      *supported = 0;
-      return NAN;
-    }
+    if (!(ta < MIR_FAST_T) || !(tb < MIR_FAST_T)) fast = 0;
   }
   double acc0[MIR_LANES] = {0}, acc1[MIR_LANES] = {0};
   long double csum = 0.0L;
@@ -551,7 +575,10 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
     csum += (long double)(half_log_2pi + (-1.0 * log(s)));
     double m = nbg > 0 ? local[nbg - 1] : 0.0;
     for (int j = nbg - 2; j >= 0; --j) m = fma(m, x, local[j]);
-    for (int k = 0; k < npk; ++k) m = fma(A[k], mir_exp2_negsq(fma(x, iw[k], cc[k])), m);
+    for (int k = 0; k < npk; ++k) {
+      const double t = fma(x, iw[k], cc[k]);
+      m = fma(A[k], fast ? mir_exp2_negsq(t) : mir_exp2_negsq_safe(t), m);
+    }
     const double r = fma(-m, w, yw);
     const size_t in_tile = i % MIR_TILE, lane = in_tile % MIR_LANES, kk = in_tile / MIR_LANES;
     if (kk & 1)

@@ -80,3 +80,31 @@ def test_adaptive_run_history_equals_mirror(mhx, orc):
         assert np.array_equal(Ls[c], w.current_l())
         assert st["best_logpost"][c] == w.best()[1]
     e.close()
+
+
+@pytest.mark.parametrize("n", [700, 5000])
+def test_guarded_exp_path_is_the_chains_own_choice(mhx, orc, n):
+    """Peaks so narrow that |t| leaves the table form's range (t^2 >= 2^23) somewhere in the data
+    send THAT chain through the guarded exp; the choice is made per wave, so the chains sharing
+    its workgroup keep their bits (no workgroup vote), and both forms equal the mirror."""
+    s = pb.two_peak(n=n, seed=21)
+    op = s.oracle(orc)
+    th = pb.perturbed(s.theta_star, 32, 0.02, seed=22)
+    narrow = [3, 4, 17, 30]
+    th[3, 4] = 1e-4      # w1: |t| up to ~1e4
+    th[4, 7] = 1e-6      # w2: |t| up to ~1e6
+    th[17, 4] = 2.0e-4
+    th[30, 7] = -3e-5    # a negative width: |t| is what counts
+    e = s.engine(mhx, 1)
+    got, parts = e.logpost(th, parts=True)
+    for i, t in enumerate(th):
+        ref, rp = op.logpost_mirror(t, parts=True)
+        assert got[i] == ref and parts[i, 0] == rp[0], (n, i)
+        assert abs(got[i] - op.logpost(t)) <= 1e-12 * op.abs_terms(t) + 2.0 ** -52 * 1e10 * 8
+    # the same vectors with the narrow ones replaced by benign ones: every other slot unchanged
+    th2 = th.copy()
+    th2[narrow] = s.theta_star
+    got2 = e.logpost(th2)
+    keep = [i for i in range(32) if i not in narrow]
+    assert np.array_equal(got[keep], got2[keep])
+    e.close()

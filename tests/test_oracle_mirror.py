@@ -30,8 +30,12 @@ def test_mirror_declines_what_the_kernel_does_differently(orc):
     s = pb.two_peak(n=100, seed=3)
     op = s.oracle(orc)
     th = s.theta_star.copy()
-    th[4] = 1e-6                     # |t| > 46000 somewhere: the kernel's guarded path
-    assert np.isnan(op.logpost_mirror(th)) and np.isfinite(op.logpost(th))
+    th[4] = 1e-6                     # |t| > kFastT somewhere: the chain's guarded path, mirrored
+    a, m = op.logpost(th), op.logpost_mirror(th)
+    assert np.isfinite(a) and abs(a - m) <= REL * op.abs_terms(th)
+    th[4] = 1e-4                     # |t| ~ 3000-8000: beyond the table form's range (2^23 > t^2)
+    a, m = op.logpost(th), op.logpost_mirror(th)
+    assert np.isfinite(a) and abs(a - m) <= REL * op.abs_terms(th)
     p = pb.poisson_peaks(n=50).oracle(orc)
     assert np.isnan(p.logpost_mirror(pb.poisson_peaks(n=50).theta_star))
 
