@@ -287,6 +287,14 @@ __device__ __forceinline__ void mexp2_negsq_head(double t, const Exp2K& K, Exp2H
   h.lo = (int)__double_as_longlong(kd);
   h.e = lds_exp2tab()[h.lo & 255];
 }
+// the same reduction for an argument s given as it is (|s| < 2^22): 2^s = tail(head)
+__device__ __forceinline__ void mexp2_head(double s, const Exp2K& K, Exp2Head& h) {
+  const double kd = s + K.magic;
+  const double kf = kd - K.magic;
+  h.r = s - kf;  // exact: both multiples of ulp(s), difference at most 2^-9
+  h.lo = (int)__double_as_longlong(kd);
+  h.e = lds_exp2tab()[h.lo & 255];
+}
 __device__ __forceinline__ double mexp2_negsq_tail(const Exp2Head& h, const Exp2K& K) {
   double a = __builtin_fma(h.r, K.q3, K.q[0]);
   a = __builtin_fma(h.r, a, K.q[1]);
@@ -305,14 +313,18 @@ __device__ __forceinline__ double mexp2_negsq(double t, const Exp2K& K) {
 // independent one every 4 (tools/microbench/fma_chain): with the stages pinned by
 // sched_barriers a wave issues back to back whatever the other waves of its SIMD do.  Each
 // chain's operations are mexp2_negsq()'s: identical bits.
-template <int N>
+// PLAIN_ODD: the arguments with odd index are exponents s (2^s), the even ones t (2^(-t t)).
+template <int N, bool PLAIN_ODD = false>
 __device__ __forceinline__ void mexp2_negsq_batch(const double (&t)[N], const bool (&on)[N],
                                                   const Exp2K& K, double (&v)[N]) {
   Exp2Head h[N];
   double a[N];
 #pragma unroll
   for (int i = 0; i < N; ++i)
-    if (on[i]) mexp2_negsq_head(t[i], K, h[i]);
+    if (on[i]) {
+      if (PLAIN_ODD && (i & 1)) mexp2_head(t[i], K, h[i]);
+      else mexp2_negsq_head(t[i], K, h[i]);
+    }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < N; ++i)
@@ -643,7 +655,136 @@ struct PeaksModel {
     bool fast;  // |t| < kFastT over the whole x range for every peak (uniform)
     bool skip;  // tile-level skipping allowed this step (see tile_mask)
     int thr[NPK];  // -(binary exponent of A_k) - 56
+    // uniform-grid recurrence (below): per peak -2 D, -D^2 and 2^(-2 D^2), D = the step of t from
+    // one point of a lane to its next (64 grid points on); rec: usable this step
+    double rm2d[NPK], rnd2[NPK], rq[NPK];
+    unsigned rmask;  // bit k: peak k goes by the recurrence this step
   };
+  // ---- Gaussians on a uniformly spaced x grid: a two-multiply recurrence ----------------------
+  // Lane l evaluates the points l, l + 64, l + 128, ... of a tile, so on a grid of spacing h its t
+  // advances by the constant D = 64 h iw from one point to the next, and
+  //     g(t + D) = 2^-(t + D)^2 = g(t) r(t),   r(t) = 2^(-2 t D - D^2),   r(t + D) = r(t) 2^(-2 D^2):
+  // per point and peak  f = fma(A, g, f); g = g r; r = r q  - 3 instructions where the direct
+  // form takes 14.  g and r are re-seeded from the direct formulas (table exp, at the lane's
+  // ACTUAL x) every kSeedSteps = 16 points of the lane, so a value is at most 15 steps away from an
+  // exactly evaluated one: r_j = r_0 q^j carries (j + 1) roundings, g_m = g_0 r_0 ... r_(m-1)
+  // m + sum_j (j + 1) <= 135 of them -> |g_m / g(t_m) - 1| <= 150 * 2^-53 = 1.7e-14, plus the
+  // grid's own departure from x_0 + i h (checked <= 8 ulp of max |x| when the dataset is set:
+  // 2 |t| iw 8 ulp).  Both are far inside the stated tolerance 1e-12 sum |term|
+  // (tests/test_gpu_recurrence.py measures them against the direct path and the oracle).
+  // Preconditions, per step and PEAK (else that peak keeps the direct form): the fast path,
+  // 16 |D| <= 1 - a seed that underflows to 0 (|t| > 33.8) then stays beyond |t| = 32.8 for its 15
+  // steps, where the true value is below 2^-1075 as well - and a dataset on a grid
+  // (FnDesc::grid_H).  (A narrow peak - large D - is left out of most tiles by tile-level
+  // skipping anyway; where it is not, t runs through it in a few points and the direct form is
+  // the right one.)
+  // The seeding cadence is fixed in points of a lane, not in tiles, so both kernel families
+  // produce the same bits.  Tile-level skipping stays exact for these values too: its bound has a
+  // factor 2 in hand (an addend below f 2^-53 cannot move f; the test asks for f 2^-54).
+  static constexpr bool kHasRec = !LORENTZ;
+  static constexpr int kSeedSteps = 16;
+  struct Rec {
+    double g[NPK], r[NPK];
+  };
+  static __device__ __forceinline__ unsigned rec_mask(const Prep& p) { return p.rmask; }
+  // x0: the lane's x at the first of the next kSeedSteps points; mask: the peaks to seed (those
+  // that are evaluated in this tile AND go by the recurrence)
+  static __device__ __forceinline__ void rec_seed(const Prep& p, double x0, unsigned mask, Rec& rs) {
+    if constexpr (NPK <= 2) {
+      double t[2 * NPK], v[2 * NPK];
+      bool on[2 * NPK];
+#pragma unroll
+      for (int k = 0; k < NPK; ++k) {
+        on[2 * k] = on[2 * k + 1] = !kHasSkip || ((mask >> k) & 1u);
+        const double ts = on[2 * k] ? fma_svv(x0, p.iw[k], p.cv[k]) : 0.0;
+        t[2 * k] = ts;
+        t[2 * k + 1] = __builtin_fma(p.rm2d[k], ts, p.rnd2[k]);
+      }
+      mexp2_negsq_batch<2 * NPK, true>(t, on, p.K, v);
+#pragma unroll
+      for (int k = 0; k < NPK; ++k)
+        if (on[2 * k]) {
+          rs.g[k] = v[2 * k];
+          rs.r[k] = v[2 * k + 1];
+        }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NPK; ++k) {
+        if (kHasSkip && !((mask >> k) & 1u)) continue;  // wave-uniform
+        double t[2], v[2];
+        const bool on[2] = {true, true};
+        t[0] = __builtin_fma(x0, p.iw[k], p.mu[k]);
+        t[1] = __builtin_fma(p.rm2d[k], t[0], p.rnd2[k]);
+        mexp2_negsq_batch<2, true>(t, on, p.K, v);
+        rs.g[k] = v[0];
+        rs.r[k] = v[1];
+      }
+    }
+  }
+  // The model at the lane's next P points on the fast path: peaks outside `mask` are left out
+  // (tile-level skipping), peaks in `rmask` advance by the recurrence, the others are evaluated
+  // directly (all of those as one batch when the masks are compile-time constants).  The peaks
+  // are added in increasing k whatever their form.
+  template <int P>
+  static __device__ __forceinline__ void eval_mixed(const Prep& p, const double (&x)[P],
+                                                    unsigned mask, unsigned rmask, Rec& rs,
+                                                    double (&f)[P]) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) f[i] = bg_of(p, x[i]);
+    if constexpr (NPK * P <= 4) {
+      double t[NPK * P], v[NPK * P];
+      bool on[NPK * P];
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < NPK; ++k)
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+          on[k * P + i] = ((mask >> k) & 1u) && !((rmask >> k) & 1u);
+          any = any || on[k * P + i];
+          t[k * P + i] = on[k * P + i] ? fma_svv(x[i], p.iw[k], p.cv[k]) : 0.0;
+        }
+      if (any) mexp2_negsq_batch<NPK * P>(t, on, p.K, v);
+#pragma unroll
+      for (int k = 0; k < NPK; ++k) {
+        if (!((mask >> k) & 1u)) continue;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+          if ((rmask >> k) & 1u) {
+            f[i] = __builtin_fma(p.A[k], rs.g[k], f[i]);
+            rs.g[k] = rs.g[k] * rs.r[k];
+            rs.r[k] = rs.r[k] * p.rq[k];
+          } else {
+            f[i] = __builtin_fma(p.A[k], v[k * P + i], f[i]);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NPK; ++k) {
+        if (!((mask >> k) & 1u)) continue;  // wave-uniform branches
+        if ((rmask >> k) & 1u) {
+#pragma unroll
+          for (int i = 0; i < P; ++i) {
+            f[i] = __builtin_fma(p.A[k], rs.g[k], f[i]);
+            rs.g[k] = rs.g[k] * rs.r[k];
+            rs.r[k] = rs.r[k] * p.rq[k];
+          }
+        } else {
+          double t[P], v[P], ck = p.mu[k];
+          asm volatile("" : "+v"(ck));
+          bool on[P];
+#pragma unroll
+          for (int i = 0; i < P; ++i) {
+            on[i] = true;
+            t[i] = fma_svv(x[i], p.iw[k], ck);
+          }
+          mexp2_negsq_batch<P>(t, on, p.K, v);
+#pragma unroll
+          for (int i = 0; i < P; ++i) f[i] = __builtin_fma(p.A[k], v[i], f[i]);
+        }
+      }
+    }
+  }
   // Tile-level skipping of Gaussian peaks, an EXACT transformation of the fast path.
   // Over a tile whose x lie in [xlo, xhi], t_k = fma(x, iw_k, c_k) is monotone in x, so
   // |t_k| >= tmin = min(|t_k(xlo)|, |t_k(xhi)|) when both ends have the same sign, hence
@@ -659,6 +800,7 @@ struct PeaksModel {
   static constexpr bool kHasSkip = !LORENTZ && NBG >= 1 && NBG <= 2 && NPK <= 30;
   static constexpr int kPeaks = NPK;
   static __device__ __forceinline__ double bg_of(const Prep& p, double x) {
+    if (NBG == 0) return 0.0;
     double f = p.bg[NBG > 0 ? NBG - 1 : 0];
 #pragma unroll
     for (int j = NBG - 2; j >= 0; --j) f = __builtin_fma(f, x, p.bg[j]);
@@ -721,6 +863,18 @@ struct PeaksModel {
     p.fast = fast;
     p.skip = skip && fast && kHasSkip;
     p.K.pin();
+    unsigned rmask = 0;
+#pragma unroll
+    for (int k = 0; k < NPK; ++k) {
+      const double dl = fn.grid_H * p.iw[k];  // D_k
+      p.rm2d[k] = uniform_f64(-2.0 * dl);
+      p.rnd2[k] = uniform_f64(-(dl * dl));
+      p.rq[k] = uniform_f64(mexp2(2.0 * p.rnd2[k]));
+      const bool ok = kHasRec && fast && fn.grid_H != 0.0 &&
+                      (fabs(dl) * (double)kSeedSteps <= 1.0);  // NaN fails
+      rmask |= ok ? (1u << k) : 0u;
+    }
+    p.rmask = (unsigned)__builtin_amdgcn_readfirstlane((int)rmask);
     return p;
   }
   static __device__ __forceinline__ bool fast_ok(const Prep& p) { return p.fast; }
@@ -894,6 +1048,17 @@ template <class M>
 struct model_peaks<M, decltype((void)M::kPeaks, void())> {
   static constexpr int value = M::kPeaks;
 };
+template <class M, class = void>
+struct model_has_rec { static constexpr bool value = false; };
+template <class M>
+struct model_has_rec<M, decltype((void)M::kHasRec, void())> {
+  static constexpr bool value = M::kHasRec;
+};
+struct NoRec {};
+template <class M, bool = model_has_rec<M>::value>
+struct model_rec_state { typedef NoRec type; };
+template <class M>
+struct model_rec_state<M, true> { typedef typename M::Rec type; };
 template <class M, class = void>
 struct model_has_eval_n { static constexpr bool value = false; };
 template <class M>

@@ -833,6 +833,22 @@ int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y, cons
     f.xmin = std::min(f.xmin, x[i]);
     f.xmax = std::max(f.xmax, x[i]);
   }
+  // A uniformly spaced x grid (spectra, histograms, time series: x_i = x_0 + i h) lets the
+  // Gaussian peaks advance by a two-multiply recurrence instead of an exp per point
+  // (PeaksModel, csrc/mhx_device.hpp).  Accepted when every x_i is within 8 ulp of max |x| of
+  // x_0 + i h with h = (x_(n-1) - x_0) / (n - 1); MHX_NO_RECURRENCE=1 keeps the direct form.
+  f.grid_H = 0.0;
+  {
+    const char* nr = getenv("MHX_NO_RECURRENCE");
+    if (!(nr && atoi(nr) != 0) && n >= 2 && std::isfinite(x[0]) && std::isfinite(x[n - 1])) {
+      const double h = (x[n - 1] - x[0]) / (double)(n - 1);
+      const double tol = 8.0 * 0x1p-52 * std::max(std::fabs(x[0]), std::fabs(x[n - 1]));
+      bool grid = h != 0.0 && std::isfinite(h);
+      for (size_t i = 0; i < n && grid; ++i)
+        grid = std::fabs(x[i] - (x[0] + (double)i * h)) <= tol;
+      if (grid) f.grid_H = 64.0 * h;
+    }
+  }
   D.set = true;
   e->problem_dirty = true;
   return MHX_OK;

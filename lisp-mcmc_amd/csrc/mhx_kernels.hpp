@@ -90,9 +90,12 @@ struct CMask {
 // parameters satisfy the model's fast-path precondition (model_has_fast) - decided per WAVE:
 // the tile pipeline and its barriers are common to both paths, only the arithmetic of the
 // wave's own points differs, so a chain's bits never depend on which chains share its workgroup.
+// rmask (wave-uniform, 0 unless fast): the peaks that go by the uniform-grid recurrence this
+// step (PeaksModel, model_has_rec).
 template <class Model, int LIK>
 __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::Prep& prep,
-                                        bool active, GroupLds& lds, bool fast = false) {
+                                        bool active, GroupLds& lds, bool fast = false,
+                                        unsigned rmask = 0u) {
   constexpr int NARR = LIK == MHX_LIK_POISSON ? 2 : (LIK == MHX_LIK_NORMAL_CUTOFF ? 4 : 3);
   static_assert(kTilePoints == 2 * kThreads, "one double2 per thread per array per tile");
   const int l = lane_id();
@@ -132,8 +135,9 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
       // One tile.  `mk` is the set of Gaussian peaks to evaluate: a run-time value, or a CMask<M>
       // whose value is a compile-time constant once the lambda is inlined - the per-peak tests
       // in PeaksModel::eval then fold away and each variant is straight-line code.
-      auto tile_body_m = [&](auto mk, auto whole) {
+      auto tile_body_m = [&](auto mk, auto rk, auto whole) {
         const unsigned mask = mk;
+        const unsigned rm = rk;  // the peaks of `mask` that go by the recurrence
         // whole tile = every point is data: the pad test of the Poisson / expression
         // likelihoods (compare + select per point) is only compiled into the ragged variant
         constexpr bool kWhole = decltype(whole)::value;
@@ -160,6 +164,8 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
         for (int sec = 0; sec < NSEC; ++sec) {
           const int sbase = sec * NIN * P * kWave;  // first tile element of this section
           if (sbase >= nv) break;
+          typename model_rec_state<Model>::type rs;  // (REC) the peaks' running g, r
+          (void)rs;
           double x[P], y[P], wv[P], cv[P];
 #pragma unroll
           for (int i = 0; i < P; ++i) {
@@ -187,7 +193,20 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the arithmetic below
             double m[P];
-            model_eval_n<Model, FAST, P>(prep, x, mask, m);
+            if constexpr (model_has_rec<Model>::value) {  // (tested on its own: generic lambda)
+              if constexpr (FAST) {
+                // re-seeded every kSeedSteps points of the lane, counted from the tile's start (a
+                // section is a whole number of seeding periods in either kernel family)
+                static_assert((NIN * P) % 16 == 0, "sections hold whole seeding periods");
+                if ((it * P) % 16 == 0 && (rm & mask) != 0u)
+                  Model::rec_seed(prep, x[0], rm & mask, rs);
+                Model::template eval_mixed<P>(prep, x, mask, rm, rs, m);
+              } else {
+                model_eval_n<Model, FAST, P>(prep, x, mask, m);
+              }
+            } else {
+              model_eval_n<Model, FAST, P>(prep, x, mask, m);
+            }
             // even points feed acc0, odd points acc1, each in increasing point order: the
             // summation order the oracle's mirror mode restates
 #pragma unroll
@@ -225,14 +244,14 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
           }
         }
       };
-      auto tile_body = [&](auto mk) {
+      auto tile_body = [&](auto mk, auto rk) {
         if constexpr (LIK == MHX_LIK_POISSON || LIK == MHX_LIK_EXPR) {
           if (gbase + kTilePoints <= f.n)
-            tile_body_m(mk, BoolC<true>{});
+            tile_body_m(mk, rk, BoolC<true>{});
           else
-            tile_body_m(mk, BoolC<false>{});
+            tile_body_m(mk, rk, BoolC<false>{});
         } else {
-          tile_body_m(mk, BoolC<true>{});  // neutral pads: nothing to test
+          tile_body_m(mk, rk, BoolC<true>{});  // neutral pads: nothing to test
         }
       };
       // Gaussian peaks that cannot change any sum of this tile by even one bit are left out
@@ -247,23 +266,33 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
             tile_masks = Model::tile_mask(prep, f.txlo[ti], f.txhi[ti]);
           }
           const unsigned tm = (unsigned)__builtin_amdgcn_readlane((int)tile_masks, (int)(t & 63));
+          // one straight-line variant per (peaks evaluated, peaks by recurrence) with <= 2 peaks
           if constexpr (Model::kPeaks == 1) {
-            if (tm & 1u) tile_body(CMask<1u>{}); else tile_body(CMask<0u>{});
+            switch ((tm & 1u) | ((rmask & tm & 1u) << 1)) {
+              case 0u: tile_body(CMask<0u>{}, CMask<0u>{}); break;
+              case 1u: tile_body(CMask<1u>{}, CMask<0u>{}); break;
+              default: tile_body(CMask<1u>{}, CMask<1u>{}); break;
+            }
           } else if constexpr (Model::kPeaks == 2) {
-            switch (tm & 3u) {
-              case 0u: tile_body(CMask<0u>{}); break;
-              case 1u: tile_body(CMask<1u>{}); break;
-              case 2u: tile_body(CMask<2u>{}); break;
-              default: tile_body(CMask<3u>{}); break;
+            switch ((tm & 3u) | ((rmask & tm & 3u) << 2)) {
+              case 0u: tile_body(CMask<0u>{}, CMask<0u>{}); break;
+              case 1u: tile_body(CMask<1u>{}, CMask<0u>{}); break;
+              case 5u: tile_body(CMask<1u>{}, CMask<1u>{}); break;
+              case 2u: tile_body(CMask<2u>{}, CMask<0u>{}); break;
+              case 10u: tile_body(CMask<2u>{}, CMask<2u>{}); break;
+              case 3u: tile_body(CMask<3u>{}, CMask<0u>{}); break;
+              case 7u: tile_body(CMask<3u>{}, CMask<1u>{}); break;
+              case 11u: tile_body(CMask<3u>{}, CMask<2u>{}); break;
+              default: tile_body(CMask<3u>{}, CMask<3u>{}); break;
             }
           } else {
-            tile_body(tm);  // more peaks: wave-uniform branches around each peak
+            tile_body(tm, rmask & tm);  // more peaks: wave-uniform branches around each peak
           }
         } else {
-          tile_body(CMask<~0u>{});
+          tile_body(CMask<~0u>{}, CMask<0u>{});
         }
       } else {
-        tile_body(CMask<~0u>{});
+        tile_body(CMask<~0u>{}, CMask<0u>{});
       }
     };
     if (active) {
@@ -361,9 +390,11 @@ struct FixedSpec {
                                                   GroupLds& lds, double*) {
     typename Model::Prep prep = Model::prepare(pf, f);
     bool fast = false;
+    unsigned rmask = 0u;
     if constexpr (model_has_fast<Model>::value)
       fast = __builtin_amdgcn_readfirstlane((int)Model::fast_ok(prep)) != 0;
-    return finish_lik<LIK>(f, sweep<Model, LIK>(f, prep, active, lds, fast));
+    if constexpr (model_has_rec<Model>::value) rmask = fast ? Model::rec_mask(prep) : 0u;
+    return finish_lik<LIK>(f, sweep<Model, LIK>(f, prep, active, lds, fast, rmask));
   }
   static __device__ __forceinline__ double logprior(const FnDesc&, const double*, double bt) {
     return bt;

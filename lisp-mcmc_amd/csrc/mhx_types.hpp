@@ -46,6 +46,8 @@ struct FnDesc {
   int64_t n_tiles;  // ceil(n / tile points of the family in use)
   double lik_const; // normal: sum_i(-1/2 log 2pi - log sigma_i); poisson: -sum_i logfact(k_i)
   double xmin, xmax; // range of x over the n points (fast-path preconditions of the models)
+  double grid_H;     // 64 h when x is a uniform grid x_0 + i h (to 8 ulp of max |x|), else 0: the
+                     // distance between two successive points of one lane (Gaussian recurrence)
   const double* txlo;  // [n_tiles] smallest / largest x of each tile (-inf / +inf when a tile
   const double* txhi;  // holds a non-finite x): what tile-level peak skipping tests against
   int32_t tile_skip;   // 0: evaluate every peak for every point (MHX_NO_TILE_SKIP=1)

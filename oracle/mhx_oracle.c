@@ -481,6 +481,62 @@ static double mir_exp2_negsq(double t) {
   return ldexp(fma(th, ee, th), (int)(lo >> 8)); /* arithmetic shift, as v_ashrrev_i32 */
 }
 
+/* csrc/mhx_device.hpp: mexp2_head + mexp2_negsq_tail = 2^s for a plain exponent s (the seeds
+ * r_0 of the uniform-grid recurrence) */
+static double mir_exp2_plain(double sx) {
+  const double MAGIC = 0x1.8p44;
+  const double q3 = 0x1.3b2ab83eadfb0p-7, q2 = 0x1.c6b0902b5a0abp-5, q1 = 0x1.ebfbdff82c585p-3,
+               q0 = 0x1.62e42fefa39d9p-1;
+  double kd = sx + MAGIC;
+  double kf = kd - MAGIC;
+  double r = sx - kf;
+  int32_t lo = (int32_t)(uint32_t)to_bits(kd);
+  const double th = mir_exp2_tab[lo & 255][0], rho = mir_exp2_tab[lo & 255][1];
+  double a = fma(r, q3, q2);
+  a = fma(r, a, q1);
+  a = fma(r, a, q0);
+  double ee = fma(r, a, rho);
+  return ldexp(fma(th, ee, th), (int)(lo >> 8));
+}
+
+/* csrc/mhx_device.hpp: mexp2 (degree-11 polynomial form; the recurrence's q = 2^(-2 D^2)) */
+static double mir_mexp2(double s) {
+  const double MAGIC = 0x1.8p52;
+  const double kd = s + MAGIC;
+  const double kf = kd - MAGIC;
+  const double f = s - kf;
+  double p = 0x1.e9d3fe3952179p-32;
+  p = fma(p, f, 0x1.e6063f7217bc6p-28);
+  p = fma(p, f, 0x1.b524fae627834p-24);
+  p = fma(p, f, 0x1.62bfd47773353p-20);
+  p = fma(p, f, 0x1.ffcbfc670dcd4p-17);
+  p = fma(p, f, 0x1.430913096fd9fp-13);
+  p = fma(p, f, 0x1.5d87fe78a5276p-10);
+  p = fma(p, f, 0x1.3b2ab6fba1ddap-7);
+  p = fma(p, f, 0x1.c6b08d704a0c2p-5);
+  p = fma(p, f, 0x1.ebfbdff82c598p-3);
+  p = fma(p, f, 0x1.62e42fefa39efp-1);
+  p = fma(p, f, 1.0);
+  if (kf != kf) return kf;
+  return ldexp(p, (int)kf);
+}
+
+/* csrc/mhx_engine.cpp, mhx_set_dataset: x is a uniform grid x_0 + i h to 8 ulp of max |x| ->
+ * 64 h (the step between two successive points of one lane), else 0 */
+static int mir_no_recurrence = 0; /* orc_mirror_set_recurrence(0): MHX_NO_RECURRENCE=1's twin */
+void orc_mirror_set_recurrence(int on) { mir_no_recurrence = !on; }
+static double mir_grid_H(const orc_fn* f) {
+  const size_t n = f->n;
+  if (mir_no_recurrence || n < 2 || !isfinite(f->x[0]) || !isfinite(f->x[n - 1])) return 0.0;
+  const double h = (f->x[n - 1] - f->x[0]) / (double)(n - 1);
+  const double a0 = fabs(f->x[0]), a1 = fabs(f->x[n - 1]);
+  const double tol = 8.0 * 0x1p-52 * (a0 > a1 ? a0 : a1);
+  if (h == 0.0 || !isfinite(h)) return 0.0;
+  for (size_t i = 0; i < n; ++i)
+    if (!(fabs(f->x[i] - (f->x[0] + (double)i * h)) <= tol)) return 0.0;
+  return 64.0 * h;
+}
+
 /* csrc/mhx_device.hpp: mexp2_negsq_safe = mexp2(max(-(t t), -1100)), the guarded form a chain
  * uses for a function whose parameters put |t| beyond kFastT somewhere in the data range */
 static double mir_exp2_negsq_safe(double t) {
@@ -566,25 +622,62 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
     double ta = fabs(fma(xmin, iw[k], cc[k])), tb = fabs(fma(xmax, iw[k], cc[k]));
     if (!(ta < MIR_FAST_T) || !(tb < MIR_FAST_T)) fast = 0;
   }
+  /* the uniform-grid recurrence (PeaksModel, "Gaussians on a uniformly spaced x grid"): per
+   * peak D = 64 h iw, r(t) = 2^(-2 t D - D^2), q = 2^(-2 D^2); a peak goes by it this step when
+   * the function is on the fast path, the data on a grid and 16 |D| <= 1.  Tile-level skipping
+   * is exact for these values as well, so - as for the direct form - it is not restated. */
+  const double gH = mir_grid_H(f);
+  double rm2d[MHX_MAX_FN_PARAMS], rnd2[MHX_MAX_FN_PARAMS], rq[MHX_MAX_FN_PARAMS];
+  int rec[MHX_MAX_FN_PARAMS];
+  for (int k = 0; k < npk; ++k) {
+    const double dl = gH * iw[k];
+    rm2d[k] = -2.0 * dl;
+    rnd2[k] = -(dl * dl);
+    rq[k] = mir_mexp2(2.0 * rnd2[k]);
+    rec[k] = fast && gH != 0.0 && (fabs(dl) * 16.0 <= 1.0);
+  }
   double acc0[MIR_LANES] = {0}, acc1[MIR_LANES] = {0};
   long double csum = 0.0L;
   const double half_log_2pi = -0.5 * log(2.0 * M_PI);
-  for (size_t i = 0; i < f->n; ++i) {
-    const double s = f->sigma[i];
-    const double w = 1.0 / s, yw = f->y[i] * w, x = f->x[i];
-    csum += (long double)(half_log_2pi + (-1.0 * log(s)));
-    double m = nbg > 0 ? local[nbg - 1] : 0.0;
-    for (int j = nbg - 2; j >= 0; --j) m = fma(m, x, local[j]);
-    for (int k = 0; k < npk; ++k) {
-      const double t = fma(x, iw[k], cc[k]);
-      m = fma(A[k], fast ? mir_exp2_negsq(t) : mir_exp2_negsq_safe(t), m);
+  for (size_t i = 0; i < f->n; ++i)
+    csum += (long double)(half_log_2pi + (-1.0 * log(f->sigma[i])));
+  /* lane l of the chain's wave takes the points l, l + 64, ... ; 16 successive points of a lane
+   * (1024 of the wave: MIR_TILE) are one seeding period of the recurrence */
+  for (size_t base = 0; base < f->n; base += MIR_TILE) {
+    for (size_t lane = 0; lane < MIR_LANES; ++lane) {
+      if (base + lane >= f->n) break;
+      double g[MHX_MAX_FN_PARAMS], r[MHX_MAX_FN_PARAMS];
+      const double x0 = f->x[base + lane];
+      for (int k = 0; k < npk; ++k)
+        if (rec[k]) {
+          const double ts = fma(x0, iw[k], cc[k]);
+          g[k] = mir_exp2_negsq(ts);
+          r[k] = mir_exp2_plain(fma(rm2d[k], ts, rnd2[k]));
+        }
+      for (size_t kk = 0; kk < MIR_TILE / MIR_LANES; ++kk) {
+        const size_t i = base + kk * MIR_LANES + lane;
+        if (i >= f->n) break;
+        const double s = f->sigma[i];
+        const double w = 1.0 / s, yw = f->y[i] * w, x = f->x[i];
+        double m = nbg > 0 ? local[nbg - 1] : 0.0;
+        for (int j = nbg - 2; j >= 0; --j) m = fma(m, x, local[j]);
+        for (int k = 0; k < npk; ++k) {
+          if (rec[k]) {
+            m = fma(A[k], g[k], m);
+            g[k] = g[k] * r[k];
+            r[k] = r[k] * rq[k];
+          } else {
+            const double t = fma(x, iw[k], cc[k]);
+            m = fma(A[k], fast ? mir_exp2_negsq(t) : mir_exp2_negsq_safe(t), m);
+          }
+        }
+        const double rr = fma(-m, w, yw);
+        if (kk & 1)
+          acc1[lane] = fma(rr, rr, acc1[lane]);
+        else
+          acc0[lane] = fma(rr, rr, acc0[lane]);
+      }
     }
-    const double r = fma(-m, w, yw);
-    const size_t in_tile = i % MIR_TILE, lane = in_tile % MIR_LANES, kk = in_tile / MIR_LANES;
-    if (kk & 1)
-      acc1[lane] = fma(r, r, acc1[lane]);
-    else
-      acc0[lane] = fma(r, r, acc0[lane]);
   }
   double v[MIR_LANES], nv[MIR_LANES];
   for (int l = 0; l < MIR_LANES; ++l) v[l] = acc0[l] + acc1[l];

@@ -82,6 +82,8 @@ void orc_problem_set_logfact_double(orc_problem* p, int flag);
 double orc_logpost(const orc_problem* p, const double* theta, double* parts);
 /* MIRROR of the GPU kernel's arithmetic (GAUSS_PEAKS + normal likelihood problems only, NaN
  * otherwise): bit-identical to the device, see mhx_oracle.c */
+/* mirror mode only: 0 = restate the kernel with MHX_NO_RECURRENCE=1 (direct exp at every point) */
+void orc_mirror_set_recurrence(int on);
 double orc_logpost_mirror(const orc_problem* p, const double* theta, double* parts);
 /* sum_i |term_i| over all likelihood points: the scale of the stated tolerance */
 double orc_logpost_abs_terms(const orc_problem* p, const double* theta);

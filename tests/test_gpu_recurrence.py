@@ -1,0 +1,178 @@
+"""Gaussian peaks on a uniformly spaced x grid advance by a two-multiply recurrence
+(csrc/mhx_device.hpp, PeaksModel: "Gaussians on a uniformly spaced x grid") instead of one exp
+per point.  Unlike tile-level skipping this is NOT a bit-exact transformation: a value is up to
+15 multiplications away from an exactly evaluated seed.  Stated bound: each peak value within
+150 * 2^-53 = 1.7e-14 (relative) of the direct form, hence the log-posterior within
+1e-13 * sum |term| of the direct kernel and, like it, within 1e-12 * sum |term| of the
+reference's arithmetic.  Checked here: against the direct kernel (MHX_NO_RECURRENCE=1), against
+the faithful oracle, bit for bit against the oracle's mirror of either form, on grids and
+non-grids, for mixtures of wide (recurrence) and narrow (direct) peaks, in both kernel families."""
+import os
+
+import numpy as np
+import pytest
+
+import problems as pb
+
+pytestmark = pytest.mark.gpu
+REL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def mhx():
+    import lisp_mcmc_amd
+    return lisp_mcmc_amd
+
+
+def engines(mhx, spec, chains, **kw):
+    """(recurrence where the data allow it, direct form everywhere); read at mhx_set_dataset"""
+    out = []
+    for flag in ("0", "1"):
+        os.environ["MHX_NO_RECURRENCE"] = flag
+        try:
+            out.append(spec.engine(mhx, chains, **kw))
+        finally:
+            os.environ.pop("MHX_NO_RECURRENCE", None)
+    return out
+
+
+def mixed_thetas(theta_star, n, seed):
+    rng = np.random.default_rng(seed)
+    th = pb.perturbed(theta_star, n, 0.03, seed=seed)
+    # widths from far below the recurrence's limit (16 * 64 h iw <= 1) to wide; peaks in and out of range
+    for r in range(4, n):
+        th[r, 4] = 10.0 ** rng.uniform(-3.5, -0.3)
+        th[r, 7] = 10.0 ** rng.uniform(-3.5, -0.3)
+        th[r, 3] = rng.uniform(-0.3, 1.3)
+        th[r, 6] = rng.uniform(-0.3, 1.3)
+        th[r, 2] = rng.choice([1.0, 0.0, 30.0, -0.5])
+    return th
+
+
+@pytest.mark.parametrize("n", [300, 1024, 1025, 5000, 100000])
+def test_logposts_recurrence_vs_direct_vs_oracle_vs_mirror(mhx, orc, n):
+    s = pb.two_peak(n=n, seed=500 + n)
+    op = s.oracle(orc)
+    rec, direct = engines(mhx, s, 1)
+    th = mixed_thetas(s.theta_star, 24, seed=n)
+    a, pa = rec.logpost(th, parts=True)
+    b, pb_ = direct.logpost(th, parts=True)
+    worst = 0.0
+    for i, t in enumerate(th):
+        scale = op.abs_terms(t)
+        assert abs(a[i] - b[i]) <= 1e-13 * scale, (n, i, a[i], b[i])
+        worst = max(worst, abs(a[i] - b[i]) / scale)
+        assert abs(a[i] - op.logpost(t)) <= REL * scale + 2.0 ** -52 * 1e10 * 8, (n, i)
+        orc.mirror_set_recurrence(True)
+        assert a[i] == op.logpost_mirror(t), (n, i)
+        orc.mirror_set_recurrence(False)
+        try:
+            assert b[i] == op.logpost_mirror(t), (n, i)
+        finally:
+            orc.mirror_set_recurrence(True)
+    assert np.array_equal(pa[:, 1], pb_[:, 1])  # the prior part does not know about any of this
+    if n >= 1024:
+        assert (a != b).any()  # ... and the recurrence really ran
+    print("n = %d: worst |rec - direct| / sum|term| = %.2e" % (n, worst))
+    rec.close()
+    direct.close()
+
+
+def test_not_a_grid_means_direct_form(mhx, orc):
+    s = pb.two_peak(n=6000, seed=77)
+    x, y, sig, lik = s.data[0]
+    rng = np.random.default_rng(5)
+    xs = np.sort(rng.uniform(0, 1, x.size))          # sorted, not equally spaced
+    s.data[0] = (xs, y, sig, lik)
+    a, b = engines(mhx, s, 1)
+    th = mixed_thetas(s.theta_star, 16, seed=3)
+    assert np.array_equal(a.logpost(th), b.logpost(th))
+    a.close()
+    b.close()
+    # one point moved by a few hundred ulp: no longer a grid either
+    s2 = pb.two_peak(n=6000, seed=77)
+    x2 = s2.data[0][0].copy()
+    x2[4000] += 3e-13
+    s2.data[0] = (x2,) + s2.data[0][1:]
+    a, b = engines(mhx, s2, 1)
+    assert np.array_equal(a.logpost(th), b.logpost(th))
+    a.close()
+    b.close()
+    # a grid far from the origin, negative spacing direction excluded (x must ascend to be found
+    # sorted by tile skipping, but the recurrence does not care): x = 2000 + i * 0.25
+    s3 = pb.lorder()  # not a peaks model: nothing changes either way
+    a, b = engines(mhx, s3, 1)
+    t3 = pb.perturbed(s3.theta_star, 4, 0.01, seed=1)
+    assert np.array_equal(a.logpost(t3), b.logpost(t3))
+    a.close()
+    b.close()
+
+
+def test_both_families_give_the_same_bits(mhx):
+    """the seeding cadence is counted in points of a lane, not in tiles"""
+    s = pb.two_peak(n=30000, seed=9)
+    th = mixed_thetas(s.theta_star, 32, seed=4)
+    got = []
+    for wpg in ("8", "16"):
+        os.environ["MHX_FAMILY_WPG"] = wpg
+        try:
+            e = s.engine(mhx, 1)
+            assert e.kernel_name().startswith("w%s/" % wpg)
+            got.append(e.logpost(th))
+            e.close()
+        finally:
+            os.environ.pop("MHX_FAMILY_WPG", None)
+    assert np.array_equal(got[0], got[1])
+
+
+def test_poisson_five_peaks_recurrence_vs_direct_vs_oracle(mhx, orc):
+    s = pb.poisson_peaks(n=40000, seed=12)
+    op = s.oracle(orc)
+    a, b = engines(mhx, s, 1)
+    th = pb.perturbed(s.theta_star, 12, 0.02, seed=6)
+    th[8:, 3] = [0.004, 0.0009, 0.2, 0.05]     # first peak's width: narrow (direct) ... wide
+    ga, gb = a.logpost(th), b.logpost(th)
+    for i, t in enumerate(th):
+        scale = op.abs_terms(t)
+        assert abs(ga[i] - gb[i]) <= 1e-13 * scale
+        assert abs(ga[i] - op.logpost(t)) <= REL * scale
+    assert (ga != gb).any()
+    # whole walks: same proposals; accept tests can differ only inside the rounding band
+    th0 = pb.perturbed(s.theta_star, 16, 0.01, seed=7)
+    l0 = np.diag(0.002 * np.abs(s.theta_star))
+    a.close()
+    b.close()
+    a, b = engines(mhx, s, 16, seed=3)
+    for e in (a, b):
+        e.init_chains(th0)
+        e.adaptive_begin(30000, 10.0, 1, l_matrix=l0)
+        e.adaptive_advance(300)
+    sa, sb = a.state(), b.state()
+    assert np.array_equal(sa["age"], sb["age"])
+    same = sum(int(np.array_equal(sa["theta"][c], sb["theta"][c])) for c in range(16))
+    assert same >= 14, same
+    for c in range(16):
+        assert abs(sa["logpost"][c] - op.logpost(sa["theta"][c])) <= REL * op.abs_terms(sa["theta"][c])
+    a.close()
+    b.close()
+
+
+def test_walk_equals_mirror_with_the_recurrence(mhx, orc):
+    """a whole walker-adaptive-steps run on a grid, against the mirror restating the recurrence"""
+    s = pb.two_peak(n=3000, seed=31)
+    op = s.oracle(orc)
+    C_, n = 4, 3000
+    e = s.engine(mhx, C_, seed=17)
+    th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=5)
+    e.init_chains(th0)
+    e.adaptive_begin(n, 10.0, 1)
+    e.adaptive_advance(1 << 40)
+    st = e.state()
+    for c in range(C_):
+        w = orc.Walker(op, th0[c], mirror=True)
+        w.adaptive_begin(n, 10.0, 1, seed=17, chain_id=c)
+        w.adaptive_advance(1 << 40)
+        th, pr = w.last()
+        assert st["age"][c] == w.age
+        assert np.array_equal(st["theta"][c], th) and st["logpost"][c] == pr, c
+    e.close()
