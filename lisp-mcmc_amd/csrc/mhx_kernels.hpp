@@ -113,6 +113,10 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
   // the engine sets FnDesc::solo only there).
   const bool solo = f.solo != 0;
   const bool have = solo && __builtin_amdgcn_readfirstlane(lds.resident) != 0;
+  // (every wave must have looked at the flag before the first one through the block below sets
+  // it: a wave that arrived late and read 1 would skip the block - its part of the DMA and the
+  // barrier - and sum over a tile that is not there yet)
+  if (solo && !have) __syncthreads();
   if (!have) {
     tile_dma<NARR>(f, 0, lds, 0, w);
     // An LDS-DMA is ordered for the readers only by the ISSUING wave's vmcnt wait followed by a
