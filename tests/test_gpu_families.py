@@ -88,3 +88,22 @@ def test_expression_kernels_in_both_families(mhx):
                                        l_matrix=np.diag([0.02, 0.02, 0.01]))
     assert mhx.walker_get(a, get=":most-likely-params") == mhx.walker_get(b, get=":most-likely-params")
     assert np.array_equal(a.engine.state()["theta"], b.engine.state()["theta"])
+
+
+def test_resident_single_tile_repeated_launches(mhx, orc):
+    """A problem of one function and one tile walked by at most one workgroup keeps its tile in
+    LDS (FnDesc::solo).  The wave that stages the tile sets a flag the others read: every launch -
+    not only the first, whose cold caches hide the race - must wait for all readers before it
+    does.  Repeated evaluations on such engines, for the 2-point and the 4-point inner loops,
+    against the oracle."""
+    for s in (pb.poisson_peaks(n=900, seed=3), pb.two_peak(n=1000, seed=4), pb.lorder()):
+        op = s.oracle(orc)
+        th = pb.perturbed(s.theta_star, 10, 0.01, seed=9)
+        ref = np.array([op.logpost(t) for t in th])
+        scale = np.array([op.abs_terms(t) for t in th])
+        for chains in (1, 2, 8):
+            e = s.engine(mhx, chains)
+            for rep in range(6):
+                got = e.logpost(th)
+                assert np.all(np.abs(got - ref) <= 1e-12 * scale), (e.kernel_name(), chains, rep)
+            e.close()
