@@ -12,8 +12,9 @@
  *                                               mhx_set_dataset / mhx_set_bounds +
  *                                               mhx_init_chains
  *   walker-make-step           M:1067-1070   -> mhx_logpost
- *   walker-take-step           M:1072-1095   -> mhx_step_injected (caller's z,u) and the
- *                                               body of mhx_adaptive_advance (Philox z,u)
+ *   walker-take-step           M:1072-1095   -> mhx_take_step (Philox z,u), mhx_step_injected
+ *                                               (caller's z,u) and the body of
+ *                                               mhx_adaptive_advance
  *   walker-adaptive-steps-full M:862-942     -> mhx_adaptive_begin / _advance / _steps_full
  *   walker-adaptive-steps      M:946-947     -> mhx_adaptive_steps
  *   walker-many-steps          M:849-853     -> mhx_many_steps
@@ -23,6 +24,8 @@
  *   create-log-liklihood-function M:402-416  -> mhx_set_likelihood_expr
  *   prior-bounds-let           M:346-369     -> mhx_set_bounds (+ mhx_set_prior_expr)
  *   mfit-walker-estop          M:860-861     -> mhx_request_stop
+ *   a list of walkers mapped in one image (M:1029-1033, nv-specific.lisp:58-66)
+ *                                            -> mhx_group_* : one host process, several GPUs
  *
  * Conventions: every function returns MHX_OK (0) or a negative MHX_E* code and never
  * throws; the message of the last failure on the calling thread is available from
@@ -49,7 +52,7 @@ using __hip_internal::uint8_t;
 extern "C" {
 #endif
 
-#define MHX_VERSION 100 /* 0.1.0 */
+#define MHX_VERSION 200 /* 0.2.0 */
 
 /* ---- limits ------------------------------------------------------------ */
 #define MHX_MAX_PARAMS 63    /* d: length of the shared parameter vector (one lane of the
@@ -235,18 +238,80 @@ int mhx_adaptive_advance(mhx_engine* e, int64_t max_iters, int64_t* n_running);
 int mhx_adaptive_steps_full(mhx_engine* e, const mhx_run_opts* o);
 /* (walker-adaptive-steps w n): n, :temperature 10, :auto :prob-settle (M:946-947). */
 int mhx_adaptive_steps(mhx_engine* e, int64_t n);
-/* walker-many-steps (M:849-853): n steps with a constant L, temperature 1.
- * L == NULL -> diag(1e-2 * median-params) is NOT reproduced; pass L. */
+/* walker-many-steps (M:849-853): n steps with a constant L, temperature 1.  The nil default
+ * of M:851, diag(1e-2 * median-params), is formed by the host shims (mhx_get_trace); pass L. */
 int mhx_many_steps(mhx_engine* e, int64_t n, const double* L, int per_chain_l);
+/* (walker-take-step w :l-matrix L :temperature T) for every chain (M:1072-1095): ONE step with
+ * the device's own randomness (Philox, the next draw of each chain).  The nil default of
+ * M:1074, diag(1e-2 * most-likely-params of the newest 1000 steps), is the shims' to form. */
+int mhx_take_step(mhx_engine* e, const double* L, int per_chain_l, double temperature);
 int mhx_request_stop(mhx_engine* e);
 
-/* Multi-rank pooled adaptation: install the all-reduce used every adaptation tick. */
+/* Multi-rank pooled adaptation through a caller-supplied sum (MPI, a test stub ...): installs the
+ * all-reduce used every adaptation tick.  The native path is RCCL: mhx_comm_init_rank (one
+ * process per GPU) or mhx_group_create (one process, several GPUs) below. */
 int mhx_set_allreduce(mhx_engine* e, mhx_allreduce_fn fn, void* ctx, int wants_device_buffer);
+
+/* ---- native RCCL (librccl.so is loaded on first use; MHX_ECOMM when it is absent) ----------
+ * One process per GPU: rank 0 calls mhx_comm_get_unique_id and hands the 128 bytes to the other
+ * ranks by whatever channel the host has (a file, MPI, torch.distributed ...); then EVERY rank
+ * calls mhx_comm_init_rank on its engine (collective: ncclCommInitRank).  From then on the
+ * pooled tick of MHX_ADAPT_POOLED is k_pool_stats -> k_pool_reduce -> ncclAllReduce(1+d+d*d
+ * doubles, sum) -> k_pool_factor, all on the engine's stream with no host synchronisation. */
+int mhx_comm_get_unique_id(uint8_t id[128]);
+int mhx_comm_init_rank(mhx_engine* e, const uint8_t id[128], int rank, int n_ranks);
+
+/* ---- one host process, several GPUs ---------------------------------------------------------
+ * The reference runs many walkers as a list mapped in ONE Lisp image (M:1029-1033); a group is
+ * that list spread over GPUs: cfg->n_chains walkers in all, contiguous global id ranges per
+ * device (mhx_group_partition; Philox counters use global ids, so the walks do not depend on the
+ * number of devices), one engine + one HIP stream per device, datasets replicated.  Every
+ * group call enqueues its launches on ALL devices before it waits for any.  With
+ * MHX_ADAPT_POOLED and more than one device the communicators come from ncclCommInitAll and the
+ * tick's all-reduce is issued for all devices inside ncclGroupStart/End.  (Engines of a group
+ * that name the SAME device - a rehearsal on one GPU - sum their statistics through the host.)
+ * cfg->device is ignored; cfg->chain_offset is the global id of the group's first chain.
+ * mhx_group_engine(g, i) exposes engine i to every per-engine entry point above (read-backs of
+ * one walker, mhx_logpost ...); problem definition goes through the mhx_group_set_* twins. */
+typedef struct mhx_group mhx_group;
+int mhx_group_partition(int64_t n_chains, int n_parts, int part, int64_t* first, int64_t* count);
+int mhx_group_create(const mhx_config* cfg, const int32_t* devices, int n_devices,
+                     mhx_group** out);
+void mhx_group_destroy(mhx_group* g);
+int mhx_group_size(const mhx_group* g);
+mhx_engine* mhx_group_engine(mhx_group* g, int i);
+int mhx_group_chain_range(const mhx_group* g, int i, int64_t* first, int64_t* count);
+int mhx_group_set_function(mhx_group* g, int k, int model_id, const int32_t* shape, int n_shape,
+                           const int32_t* param_index, int n_index);
+int mhx_group_set_dataset(mhx_group* g, int k, const double* x, const double* y,
+                          const double* sigma, size_t n, int likelihood);
+int mhx_group_set_bounds(mhx_group* g, int k, const int32_t* idx, const double* lo,
+                         const double* hi, int n);
+int mhx_group_set_function_expr(mhx_group* g, int k, const char* expr,
+                                const char* const* param_names, const int32_t* param_index,
+                                int n_index);
+int mhx_group_set_prior_expr(mhx_group* g, int k, const char* expr, const char* const* names,
+                             const int32_t* index, int n);
+int mhx_group_set_likelihood_expr(mhx_group* g, int k, const char* expr);
+/* theta0: [cfg->n_chains][d] in global chain order, or [d] when broadcast != 0 */
+int mhx_group_init_chains(mhx_group* g, const double* theta0, int broadcast);
+int mhx_group_adaptive_begin(mhx_group* g, const mhx_run_opts* o);
+int mhx_group_adaptive_advance(mhx_group* g, int64_t max_iters, int64_t* n_running);
+int mhx_group_adaptive_steps_full(mhx_group* g, const mhx_run_opts* o);
+int mhx_group_request_stop(mhx_group* g);
+/* gathered in global chain order; any pointer may be NULL */
+int mhx_group_get_state(mhx_group* g, double* theta, double* logpost, double* best_theta,
+                        double* best_logpost, int64_t* length, int64_t* age);
+int mhx_group_get_counters(mhx_group* g, uint64_t* chain_steps, uint64_t* kernel_launches);
 
 /* ---- read-back (walker-get, M:487-543) ------------------------------------ */
 /* Any pointer may be NULL.  theta/best_theta [n_chains][d]; others [n_chains]. */
 int mhx_get_state(mhx_engine* e, double* theta, double* logpost, double* best_theta,
                   double* best_logpost, int64_t* length, int64_t* age);
+/* The same for ONE chain (what the accessors of one walker need: walker-last-step,
+ * walker-most-likely-step, walker-length, walker-age): d doubles instead of n_chains * d. */
+int mhx_get_chain(mhx_engine* e, int64_t chain, double* theta, double* logpost,
+                  double* best_theta, double* best_logpost, int64_t* length, int64_t* age);
 int mhx_get_chain_status(mhx_engine* e, int32_t* status, int64_t* loop_index);
 int mhx_get_lmatrix(mhx_engine* e, double* L /* [n_chains][d][d] */);
 int mhx_get_temperature(mhx_engine* e, double* T /* [n_chains] */);

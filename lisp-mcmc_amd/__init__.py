@@ -11,7 +11,7 @@ importlib.import_module("lisp-mcmc_amd").
 """
 from . import _capi as capi  # noqa: F401
 from ._capi import MhxError  # noqa: F401
-from .engine import Engine  # noqa: F401
+from .engine import Engine, Group, comm_unique_id, partition  # noqa: F401
 from . import models  # noqa: F401
 from . import sexpr  # noqa: F401
 from . import distributed  # noqa: F401
@@ -24,7 +24,7 @@ from .walker import (  # noqa: F401
     walker_modify, prior_bounds, log_prior_flat, request_stop, create_log_liklihood_function,
 )
 
-__all__ = ["capi", "MhxError", "Engine", "models", "Walker", "WalkerStep", "walker_create",
+__all__ = ["capi", "MhxError", "Engine", "Group", "comm_unique_id", "partition", "models", "Walker", "WalkerStep", "walker_create",
            "mcmc_fit", "walker_adaptive_steps", "walker_adaptive_steps_full",
            "walker_many_steps", "walker_take_step", "walker_get", "walker_modify",
            "prior_bounds", "log_prior_flat", "request_stop", "create_log_liklihood_function"]

@@ -81,6 +81,31 @@ SIGNATURES = {
     "mhx_get_counters": (C.c_int, [C.c_void_p, u64p, u64p]),
     "mhx_kernel_name": (C.c_char_p, [C.c_void_p]),
     "mhx_kernel_timing": (C.c_int, [C.c_void_p, C.c_int, f64p, u64p, f64p]),
+    "mhx_take_step": (C.c_int, [C.c_void_p, f64p, C.c_int, C.c_double]),
+    "mhx_get_chain": (C.c_int, [C.c_void_p, C.c_int64, f64p, f64p, f64p, f64p, i64p, i64p]),
+    "mhx_comm_get_unique_id": (C.c_int, [u8p]),
+    "mhx_comm_init_rank": (C.c_int, [C.c_void_p, u8p, C.c_int, C.c_int]),
+    "mhx_group_partition": (C.c_int, [C.c_int64, C.c_int, C.c_int, i64p, i64p]),
+    "mhx_group_create": (C.c_int, [C.POINTER(Config), i32p, C.c_int, C.POINTER(C.c_void_p)]),
+    "mhx_group_destroy": (None, [C.c_void_p]),
+    "mhx_group_size": (C.c_int, [C.c_void_p]),
+    "mhx_group_engine": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "mhx_group_chain_range": (C.c_int, [C.c_void_p, C.c_int, i64p, i64p]),
+    "mhx_group_set_function": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i32p, C.c_int, i32p, C.c_int]),
+    "mhx_group_set_dataset": (C.c_int, [C.c_void_p, C.c_int, f64p, f64p, f64p, C.c_size_t, C.c_int]),
+    "mhx_group_set_bounds": (C.c_int, [C.c_void_p, C.c_int, i32p, f64p, f64p, C.c_int]),
+    "mhx_group_set_function_expr": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p,
+                                              C.POINTER(C.c_char_p), i32p, C.c_int]),
+    "mhx_group_set_prior_expr": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p,
+                                           C.POINTER(C.c_char_p), i32p, C.c_int]),
+    "mhx_group_set_likelihood_expr": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p]),
+    "mhx_group_init_chains": (C.c_int, [C.c_void_p, f64p, C.c_int]),
+    "mhx_group_adaptive_begin": (C.c_int, [C.c_void_p, C.POINTER(RunOpts)]),
+    "mhx_group_adaptive_advance": (C.c_int, [C.c_void_p, C.c_int64, i64p]),
+    "mhx_group_adaptive_steps_full": (C.c_int, [C.c_void_p, C.POINTER(RunOpts)]),
+    "mhx_group_request_stop": (C.c_int, [C.c_void_p]),
+    "mhx_group_get_state": (C.c_int, [C.c_void_p, f64p, f64p, f64p, f64p, i64p, i64p]),
+    "mhx_group_get_counters": (C.c_int, [C.c_void_p, u64p, u64p]),
 }
 
 _lib = None

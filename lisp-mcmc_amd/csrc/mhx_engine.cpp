@@ -15,6 +15,8 @@
 #include <vector>
 
 #include "../../include/mhx.h"
+#include <dlfcn.h>
+
 #include <memory>
 
 #include "mhx_launch.hpp"
@@ -77,6 +79,51 @@ struct Dataset {
 
 int64_t steps_to_settle_of(int d) { return 10 * (int64_t)std::max(50, d); }  // M:873
 
+// ---- RCCL, loaded lazily (libmhx.so has no link-time dependency on it: a single-GPU host needs
+// no collective library).  Only what the pooled-covariance tick uses; the types are restated
+// from rccl.h (NCCL ABI: opaque communicator, 128-byte id, ncclDouble = 8, ncclSum = 0).
+typedef struct mhxNcclComm* nccl_comm_t;
+struct nccl_unique_id { char internal[128]; };
+struct Rccl {
+  void* h = nullptr;
+  int (*GetUniqueId)(nccl_unique_id*) = nullptr;
+  int (*CommInitRank)(nccl_comm_t*, int, nccl_unique_id, int) = nullptr;
+  int (*CommInitAll)(nccl_comm_t*, int, const int*) = nullptr;
+  int (*CommDestroy)(nccl_comm_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+Rccl& rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r;
+  tried = true;
+  // the soname first: a host that already has RCCL loaded (PyTorch does) shares that instance
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names) {
+    r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (r.h) break;
+  }
+  if (!r.h) return r;
+#define SYM(field, name) *(void**)(&r.field) = dlsym(r.h, name)
+  SYM(GetUniqueId, "ncclGetUniqueId");
+  SYM(CommInitRank, "ncclCommInitRank");
+  SYM(CommInitAll, "ncclCommInitAll");
+  SYM(CommDestroy, "ncclCommDestroy");
+  SYM(AllReduce, "ncclAllReduce");
+  SYM(GroupStart, "ncclGroupStart");
+  SYM(GroupEnd, "ncclGroupEnd");
+  SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+  r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllReduce &&
+         r.GroupStart && r.GroupEnd;
+  return r;
+}
+constexpr int kNcclDouble = 8, kNcclSum = 0;
+
 int pow2_ceil(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -130,13 +177,25 @@ struct mhx_engine {
   bool chains_ready = false;
 
   RunDesc R{};
-  DevBuf<double> temps;
+  DevBuf<double> temps;          // a window of the temperature schedule (ensure_temps)
+  int64_t temps_count = 0;       // entries held on the device, from R.temps_first
+  double run_temperature = 1.0;  // :temperature of the current run
   bool run_ready = false;
   int64_t chunk_iters = 64;
 
   mhx_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
   int allreduce_device = 0;
+  // native collective of the pooled tick: an RCCL communicator of this engine's own
+  // (mhx_comm_init_rank: one process per GPU) or its group's (mhx_group_create)
+  nccl_comm_t comm = nullptr;
+  bool comm_owned = false;
+  bool launch_open = false;  // steps enqueued by launch_steps_enqueue(), not yet finished
+  int64_t launch_iters = 0;
+
+  // device staging of the host-facing calls (mhx_logpost, mhx_step_injected, read-backs): grown
+  // on demand and kept, instead of a hipMalloc / hipFree pair per call
+  DevBuf<unsigned char> stage;
 
   // accounting
   uint64_t launches = 0;
@@ -529,6 +588,16 @@ void drop_split_graph(mhx_engine* e) {
   e->split_graph_plain = -1;
 }
 
+// `bytes` of staging memory, 256-byte aligned pieces carved by the caller
+int ensure_stage(mhx_engine* e, size_t bytes) {
+  if (e->stage.n >= bytes) return MHX_OK;
+  const size_t want = std::max<size_t>(bytes, 2 * e->stage.n);
+  if (e->stage.alloc(want, false) != hipSuccess)
+    return fail(MHX_ENOMEM, "hipMalloc of %zu staging bytes failed", want);
+  return MHX_OK;
+}
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
 int count_running(mhx_engine* e, int64_t* n_running) {
   std::vector<int32_t> st((size_t)e->cfg.n_chains);
   HIP_TRY(hipMemcpy(st.data(), e->status.p, st.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -538,8 +607,53 @@ int count_running(mhx_engine* e, int64_t* n_running) {
   return MHX_OK;
 }
 
-// one timed launch of the fused step kernel
-int launch_steps(mhx_engine* e, int64_t iters, int plain) {
+// The temperature schedule of M:878, entries [lo, hi): (max 1 (* (cos (* x pi (+ 1 (* 2 (floor
+// temp-steps 5000))) (/ (* 2 temp-steps)))) temperature)), products left to right, the rational
+// factor converted to double.  The device holds a WINDOW of it over the loop indices the next
+// launch can reach (every running chain that still anneals has loop index 1 + iterations since
+// begin), so a run with n = 1e9 "until stopped" costs 32 MB, not 8 GB.
+const int64_t kTempsWindow = [] {  // MHX_TEMPS_WINDOW: a small window for tests of the sliding
+  const char* s = getenv("MHX_TEMPS_WINDOW");
+  const long long v = s ? atoll(s) : 0;
+  return (int64_t)(v >= 16 ? v : (1 << 22));
+}();
+int ensure_temps(mhx_engine* e, int64_t lo, int64_t hi) {
+  RunDesc& R = e->R;
+  hi = std::min(hi, R.temp_steps);
+  if (lo >= hi) return MHX_OK;  // beyond the schedule: nothing is read
+  if (lo >= R.temps_first && hi <= R.temps_first + e->temps_count) return MHX_OK;
+  const int64_t top = std::min(R.temp_steps, lo + std::max<int64_t>(hi - lo, kTempsWindow));
+  std::vector<double> temps((size_t)(top - lo));
+  const double kfac = (double)(1 + 2 * (R.temp_steps / 5000));
+  const double inv = 1.0 / (double)(2 * R.temp_steps);
+  for (int64_t x = lo; x < top; ++x) {
+    const double arg = (((double)x * M_PI) * kfac) * inv;
+    const double v = std::cos(arg) * e->run_temperature;
+    temps[(size_t)(x - lo)] = v > 1.0 ? v : 1.0;
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));  // (a launch may still be reading the old window)
+  if ((int64_t)e->temps.n < top - lo && e->temps.alloc(temps.size(), false) != hipSuccess)
+    return fail(MHX_ENOMEM, "hipMalloc(temperature schedule, %zu) failed", temps.size());
+  HIP_TRY(hipMemcpy(e->temps.p, temps.data(), temps.size() * sizeof(double), hipMemcpyHostToDevice));
+  R.temps = e->temps.p;
+  R.temps_first = lo;
+  e->temps_count = top - lo;
+  drop_split_graph(e);  // the run description is frozen into captured launches
+  return MHX_OK;
+}
+
+// one timed launch of the fused step kernel: enqueue (returns without waiting, so that a group
+// keeps every GPU busy at once) and finish (waits for it and does the accounting)
+int launch_steps_finish(mhx_engine* e);
+int launch_steps_enqueue(mhx_engine* e, int64_t iters, int plain) {
+  if (e->launch_open) {
+    const int rc = launch_steps_finish(e);
+    if (rc != MHX_OK) return rc;
+  }
+  if (!plain) {
+    const int rc = ensure_temps(e, e->global_iter + 1, e->global_iter + 1 + iters);
+    if (rc != MHX_OK) return rc;
+  }
   HIP_TRY(hipEventRecord(e->ev0, e->stream));
   if (e->split_slices > 0) {
     // split mode: prime (first half of iteration 1), then per iteration the sweep over all
@@ -601,6 +715,14 @@ int launch_steps(mhx_engine* e, int64_t iters, int plain) {
     HIP_TRY(do_adaptive(e, iters, plain));
   }
   HIP_TRY(hipEventRecord(e->ev1, e->stream));
+  e->launch_open = true;
+  e->launch_iters = iters;
+  return MHX_OK;
+}
+int launch_steps_finish(mhx_engine* e) {
+  if (!e->launch_open) return MHX_OK;
+  e->launch_open = false;
+  HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipEventSynchronize(e->ev1));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
@@ -609,18 +731,50 @@ int launch_steps(mhx_engine* e, int64_t iters, int plain) {
   e->launches++;
   // keep a launch near 50 ms so the stop flag and the host stay responsive
   if (ms > 0.f) {
-    double per_iter = ms / (double)iters;
+    double per_iter = ms / (double)std::max<int64_t>(e->launch_iters, 1);
     int64_t want = (int64_t)(50.0 / std::max(per_iter, 1e-6));
     e->chunk_iters = std::min<int64_t>(std::max<int64_t>(want, 8), 1 << 16);
   }
   return MHX_OK;
 }
+int launch_steps(mhx_engine* e, int64_t iters, int plain) {
+  const int rc = launch_steps_enqueue(e, iters, plain);
+  return rc != MHX_OK ? rc : launch_steps_finish(e);
+}
 
 // Pooled adaptation tick (MHX_ADAPT_POOLED): per-chain displacement statistics -> sum over the
 // chains of this rank (fixed order) -> all-reduce over ranks (caller's hook: RCCL through
 // torch.distributed, or any MPI-like sum) -> covariance, Cholesky, 2.38^2/d on every rank.
+// (with an RCCL communicator everything stays on the engine's stream: no host synchronisation
+// between the statistics kernels, the all-reduce and the factorisation)
+int pool_enqueue_stats(mhx_engine* e) {
+  HIP_TRY(e->fam->pool_stats(e->stream, e->S, e->R));
+  HIP_TRY(e->fam->pool_reduce(e->stream, e->S));
+  return MHX_OK;
+}
+int pool_enqueue_allreduce(mhx_engine* e) {  // inside ncclGroupStart/End when a group drives it
+  const size_t E = 1 + (size_t)e->P.d + (size_t)e->P.d * e->P.d;
+  const int rc = rccl().AllReduce(e->pool_vec.p, e->pool_vec.p, E, kNcclDouble, kNcclSum, e->comm,
+                                  e->stream);
+  if (rc != 0)
+    return fail(MHX_ECOMM, "ncclAllReduce: %s",
+                rccl().GetErrorString ? rccl().GetErrorString(rc) : "error");
+  return MHX_OK;
+}
+int pool_enqueue_factor(mhx_engine* e) {
+  HIP_TRY(e->fam->pool_factor(e->stream, e->S));
+  e->launches += 3;
+  e->pool_refreshes++;
+  return MHX_OK;
+}
 int pool_refresh(mhx_engine* e) {
   const size_t E = 1 + (size_t)e->P.d + (size_t)e->P.d * e->P.d;
+  if (e->comm) {
+    int rc = pool_enqueue_stats(e);
+    if (rc == MHX_OK) rc = pool_enqueue_allreduce(e);
+    if (rc == MHX_OK) rc = pool_enqueue_factor(e);
+    return rc;  // stream-ordered before the next step launch
+  }
   HIP_TRY(e->fam->pool_stats(e->stream, e->S, e->R));
   HIP_TRY(e->fam->pool_reduce(e->stream, e->S));
   if (e->allreduce) {
@@ -733,6 +887,8 @@ void mhx_destroy(mhx_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->comm && e->comm_owned && rccl().ok) (void)rccl().CommDestroy(e->comm);
+  e->comm = nullptr;
   drop_split_graph(e);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -982,16 +1138,18 @@ int mhx_logpost(mhx_engine* e, const double* theta, size_t n, double* out, doubl
   if ((rc = finalize_problem(e)) != MHX_OK) return rc;
   if (n == 0) return MHX_OK;
   const int d = e->P.d;
-  DevBuf<double> dth, dout, dparts;
-  if (dth.alloc(n * d, false) != hipSuccess || dout.alloc(n, false) != hipSuccess ||
-      dparts.alloc(2 * n, false) != hipSuccess)
-    return fail(MHX_ENOMEM, "hipMalloc for %zu parameter vectors failed", n);
-  HIP_TRY(hipMemcpy(dth.p, theta, n * d * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(do_logpost(e, dth.p, (int64_t)n, dout.p, dparts.p));
+  const size_t o_th = 0, o_out = align256(n * d * sizeof(double)),
+               o_parts = o_out + align256(n * sizeof(double));
+  if ((rc = ensure_stage(e, o_parts + 2 * n * sizeof(double))) != MHX_OK) return rc;
+  double* dth = reinterpret_cast<double*>(e->stage.p + o_th);
+  double* dout = reinterpret_cast<double*>(e->stage.p + o_out);
+  double* dparts = reinterpret_cast<double*>(e->stage.p + o_parts);
+  HIP_TRY(hipMemcpy(dth, theta, n * d * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(do_logpost(e, dth, (int64_t)n, dout, dparts));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->launches++;
-  HIP_TRY(hipMemcpy(out, dout.p, n * sizeof(double), hipMemcpyDeviceToHost));
-  if (parts) HIP_TRY(hipMemcpy(parts, dparts.p, 2 * n * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, dout, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (parts) HIP_TRY(hipMemcpy(parts, dparts, 2 * n * sizeof(double), hipMemcpyDeviceToHost));
   return MHX_OK;
 }
 
@@ -1003,21 +1161,24 @@ int mhx_step_injected(mhx_engine* e, const double* L, int per_chain_l, const dou
   if (rc != MHX_OK) return rc;
   if ((rc = finalize_problem(e)) != MHX_OK) return rc;
   const size_t C = (size_t)e->cfg.n_chains, d = (size_t)e->P.d;
-  DevBuf<double> dL, dz, du, dT;
-  DevBuf<unsigned char> dacc;
   const size_t nL = (per_chain_l ? C : 1) * d * d;
-  if (dL.alloc(nL, false) != hipSuccess || dz.alloc(C * d, false) != hipSuccess ||
-      du.alloc(C, false) != hipSuccess || dT.alloc(C, false) != hipSuccess ||
-      dacc.alloc(C) != hipSuccess)
-    return fail(MHX_ENOMEM, "hipMalloc for injected randomness failed");
-  HIP_TRY(hipMemcpy(dL.p, L, nL * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dz.p, z, C * d * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(du.p, u, C * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dT.p, T, C * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(do_step_injected(e, dL.p, per_chain_l, dz.p, du.p, dT.p, dacc.p));
+  const size_t o_z = align256(nL * sizeof(double)), o_u = o_z + align256(C * d * sizeof(double)),
+               o_T = o_u + align256(C * sizeof(double)), o_acc = o_T + align256(C * sizeof(double));
+  if ((rc = ensure_stage(e, o_acc + C)) != MHX_OK) return rc;
+  double* dL = reinterpret_cast<double*>(e->stage.p);
+  double* dz = reinterpret_cast<double*>(e->stage.p + o_z);
+  double* du = reinterpret_cast<double*>(e->stage.p + o_u);
+  double* dT = reinterpret_cast<double*>(e->stage.p + o_T);
+  unsigned char* dacc = e->stage.p + o_acc;
+  HIP_TRY(hipMemcpy(dL, L, nL * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dz, z, C * d * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(du, u, C * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dT, T, C * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(dacc, 0, C));
+  HIP_TRY(do_step_injected(e, dL, per_chain_l, dz, du, dT, dacc));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->launches++;
-  if (accepted_out) HIP_TRY(hipMemcpy(accepted_out, dacc.p, C, hipMemcpyDeviceToHost));
+  if (accepted_out) HIP_TRY(hipMemcpy(accepted_out, dacc, C, hipMemcpyDeviceToHost));
   return MHX_OK;
 }
 
@@ -1053,20 +1214,12 @@ int mhx_adaptive_begin(mhx_engine* e, const mhx_run_opts* o) {
   R.adapt_mode = e->cfg.adapt_mode;
   R.stop_flag = e->stop_flag.p;
   if (R.has_mwl && R.mwl < 1) return fail(MHX_EINVAL, "max_walker_length must be >= 2");
-  // temps M:878: (max 1 (* (cos (* x pi (+ 1 (* 2 (floor temp-steps 5000))) (/ (* 2 temp-steps))))
-  // temperature)), products left to right, the rational factor converted to double
-  std::vector<double> temps((size_t)R.temp_steps);
-  const double kfac = (double)(1 + 2 * (R.temp_steps / 5000));
-  const double inv = 1.0 / (double)(2 * R.temp_steps);
-  for (int64_t x = 0; x < R.temp_steps; ++x) {
-    const double arg = (((double)x * M_PI) * kfac) * inv;
-    const double v = std::cos(arg) * o->temperature;
-    temps[(size_t)x] = v > 1.0 ? v : 1.0;
-  }
-  if (e->temps.alloc(temps.size(), false) != hipSuccess)
-    return fail(MHX_ENOMEM, "hipMalloc(temperature schedule, %zu) failed", temps.size());
-  HIP_TRY(hipMemcpy(e->temps.p, temps.data(), temps.size() * sizeof(double), hipMemcpyHostToDevice));
-  R.temps = e->temps.p;
+  // temps M:878: the first window now, the rest as the loop gets there (ensure_temps)
+  e->run_temperature = o->temperature;
+  e->temps_count = 0;
+  R.temps_first = 0;
+  e->global_iter = 0;
+  if ((rc = ensure_temps(e, 0, std::min<int64_t>(R.temp_steps, kTempsWindow))) != MHX_OK) return rc;
   HIP_TRY(hipMemset(e->stop_flag.p, 0, sizeof(int32_t)));  // (setf mfit-walker-estop nil) M:865
   const size_t C = (size_t)e->cfg.n_chains, dd = (size_t)d * d;
   if (o->l_matrix) {
@@ -1105,9 +1258,21 @@ int mhx_adaptive_advance(mhx_engine* e, int64_t max_iters, int64_t* n_running) {
       left -= now;
       if (e->global_iter % 200 == 0 && (rc = pool_refresh(e)) != MHX_OK) return rc;
     }
-  } else if (max_iters > 0) {
-    if ((rc = launch_steps(e, max_iters, 0)) != MHX_OK) return rc;
-    e->global_iter += max_iters;
+  } else {
+    // (one launch per call unless it would outrun the schedule window: then window by window,
+    // looking at the chains in between - "until done" is asked for as 2^40 iterations)
+    int64_t left = max_iters;
+    while (left > 0) {
+      const int64_t now = std::min(left, kTempsWindow);
+      if ((rc = launch_steps(e, now, 0)) != MHX_OK) return rc;
+      e->global_iter += now;
+      left -= now;
+      if (left > 0) {
+        int64_t running = 0;
+        if ((rc = count_running(e, &running)) != MHX_OK) return rc;
+        if (running == 0) break;
+      }
+    }
   }
   if (n_running) return count_running(e, n_running);
   return MHX_OK;
@@ -1132,8 +1297,23 @@ int mhx_adaptive_steps(mhx_engine* e, int64_t n) {
   return mhx_adaptive_steps_full(e, &o);
 }
 
+static int plain_steps(mhx_engine* e, int64_t n, const double* L, int per_chain_l, double T);
+
 int mhx_many_steps(mhx_engine* e, int64_t n, const double* L, int per_chain_l) {
-  if (!e || !L) return fail(MHX_EINVAL, "NULL argument (the nil-L default of M:851 is not reproduced)");
+  return plain_steps(e, n, L, per_chain_l, 1.0);
+}
+
+int mhx_take_step(mhx_engine* e, const double* L, int per_chain_l, double temperature) {
+  if (!(temperature > 0.0) || !std::isfinite(temperature))
+    return fail(MHX_EINVAL, "temperature must be finite and > 0");
+  return plain_steps(e, 1, L, per_chain_l, temperature);
+}
+
+// (dotimes (i n) (walker-take-step w :l-matrix L :temperature T)) M:852-853, M:1072-1095
+static int plain_steps(mhx_engine* e, int64_t n, const double* L, int per_chain_l, double T) {
+  if (!e || !L)
+    return fail(MHX_EINVAL, "NULL argument (the nil :l-matrix defaults of M:851 / M:1074 are "
+                            "formed by the host shims from mhx_get_trace)");
   if (!e->chains_ready) return fail(MHX_ESTATE, "mhx_init_chains has not been called");
   if (n < 0) return fail(MHX_EINVAL, "n < 0");
   int rc = use_device(e);
@@ -1162,7 +1342,7 @@ int mhx_many_steps(mhx_engine* e, int64_t n, const double* L, int per_chain_l) {
   {
     std::vector<int64_t> zero(C, 0);
     std::vector<int32_t> st(C), run(C, MHX_CHAIN_RUNNING);
-    std::vector<double> one(C, 1.0);
+    std::vector<double> one(C, T);
     HIP_TRY(hipMemcpy(st.data(), e->status.p, C * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (size_t c = 0; c < C; ++c)
       if (st[c] == MHX_CHAIN_FP_TRAP) run[c] = MHX_CHAIN_FP_TRAP;
@@ -1214,6 +1394,25 @@ int mhx_get_state(mhx_engine* e, double* theta, double* logpost, double* best_th
   return MHX_OK;
 }
 
+int mhx_get_chain(mhx_engine* e, int64_t chain, double* theta, double* logpost,
+                  double* best_theta, double* best_logpost, int64_t* length, int64_t* age) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  if (!e->chains_ready) return fail(MHX_ESTATE, "mhx_init_chains has not been called");
+  if (chain < 0 || chain >= e->cfg.n_chains) return fail(MHX_EINVAL, "chain out of range");
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  const size_t d = (size_t)e->P.d, c = (size_t)chain;
+  if (theta) HIP_TRY(hipMemcpy(theta, e->theta.p + c * d, d * sizeof(double), hipMemcpyDeviceToHost));
+  if (logpost) HIP_TRY(hipMemcpy(logpost, e->prob.p + c, sizeof(double), hipMemcpyDeviceToHost));
+  if (best_theta)
+    HIP_TRY(hipMemcpy(best_theta, e->best_theta.p + c * d, d * sizeof(double), hipMemcpyDeviceToHost));
+  if (best_logpost)
+    HIP_TRY(hipMemcpy(best_logpost, e->best_prob.p + c, sizeof(double), hipMemcpyDeviceToHost));
+  if (length) HIP_TRY(hipMemcpy(length, e->length.p + c, sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (age) HIP_TRY(hipMemcpy(age, e->age.p + c, sizeof(int64_t), hipMemcpyDeviceToHost));
+  return MHX_OK;
+}
+
 int mhx_get_chain_status(mhx_engine* e, int32_t* status, int64_t* loop_index) {
   if (!e) return fail(MHX_EINVAL, "engine is NULL");
   int rc = use_device(e);
@@ -1250,12 +1449,12 @@ int mhx_get_acceptance(mhx_engine* e, int take, double* out) {
   if (take > e->S.R) return fail(MHX_EINVAL, "take %d exceeds history_capacity %d", take, e->S.R);
   int rc = use_device(e);
   if (rc != MHX_OK) return rc;
-  DevBuf<double> d;
   const size_t C = (size_t)e->cfg.n_chains;
-  if (d.alloc(C, false) != hipSuccess) return fail(MHX_ENOMEM, "hipMalloc failed");
-  HIP_TRY(e->fam->acceptance(e->stream, e->S, take, d.p));
+  if ((rc = ensure_stage(e, C * sizeof(double))) != MHX_OK) return rc;
+  double* d = reinterpret_cast<double*>(e->stage.p);
+  HIP_TRY(e->fam->acceptance(e->stream, e->S, take, d));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  HIP_TRY(hipMemcpy(out, d.p, C * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, d, C * sizeof(double), hipMemcpyDeviceToHost));
   return MHX_OK;
 }
 
@@ -1275,18 +1474,27 @@ int mhx_get_trace(mhx_engine* e, int64_t chain, int take, double* prob, double* 
   int t = (int)std::min<int64_t>(avail, take);
   if (n_out) *n_out = t;
   if (t == 0) return MHX_OK;
-  std::vector<double> hp((size_t)Rcap), ht;
-  HIP_TRY(hipMemcpy(hp.data(), e->hist_prob.p + chain * Rcap, (size_t)Rcap * sizeof(double),
-                    hipMemcpyDeviceToHost));
+  // the newest t entries are ring slots (nh - t) ... (nh - 1) modulo the capacity: one or two
+  // contiguous runs - only those are copied, oldest first, and turned round on the host
+  const int64_t lo = (nh - t) & (int64_t)(Rcap - 1);
+  const int64_t run1 = std::min<int64_t>(t, Rcap - lo), run2 = t - run1;
+  std::vector<double> hp((size_t)t), ht;
+  const double* rp = e->hist_prob.p + chain * Rcap;
+  HIP_TRY(hipMemcpy(hp.data(), rp + lo, (size_t)run1 * sizeof(double), hipMemcpyDeviceToHost));
+  if (run2 > 0)
+    HIP_TRY(hipMemcpy(hp.data() + run1, rp, (size_t)run2 * sizeof(double), hipMemcpyDeviceToHost));
   if (theta) {
-    ht.resize((size_t)Rcap * d);
-    HIP_TRY(hipMemcpy(ht.data(), e->hist_theta.p + chain * Rcap * d,
-                      (size_t)Rcap * d * sizeof(double), hipMemcpyDeviceToHost));
+    ht.resize((size_t)t * d);
+    const double* rt = e->hist_theta.p + chain * Rcap * d;
+    HIP_TRY(hipMemcpy(ht.data(), rt + lo * d, (size_t)run1 * d * sizeof(double), hipMemcpyDeviceToHost));
+    if (run2 > 0)
+      HIP_TRY(hipMemcpy(ht.data() + run1 * d, rt, (size_t)run2 * d * sizeof(double),
+                        hipMemcpyDeviceToHost));
   }
-  for (int s = 0; s < t; ++s) {
-    const int slot = (int)((nh - 1 - s) & (Rcap - 1));
-    if (prob) prob[s] = hp[(size_t)slot];
-    if (theta) memcpy(theta + (size_t)s * d, &ht[(size_t)slot * d], sizeof(double) * d);
+  for (int s = 0; s < t; ++s) {  // s = 0 is the newest = the last one copied
+    const size_t src = (size_t)(t - 1 - s);
+    if (prob) prob[s] = hp[src];
+    if (theta) memcpy(theta + (size_t)s * d, &ht[src * d], sizeof(double) * d);
   }
   return MHX_OK;
 }
@@ -1301,18 +1509,21 @@ int mhx_get_proposal_factor(mhx_engine* e, int64_t chain, int take, double* L_ou
   int rc = use_device(e);
   if (rc != MHX_OK) return rc;
   const size_t dd = (size_t)e->P.d * e->P.d;
-  DevBuf<int32_t> fwd, info;
-  DevBuf<double> cov, out;
-  if (fwd.alloc((size_t)take) != hipSuccess || info.alloc(2) != hipSuccess ||
-      cov.alloc(dd) != hipSuccess || out.alloc(dd) != hipSuccess)
-    return fail(MHX_ENOMEM, "hipMalloc failed");
-  HIP_TRY(e->fam->l_matrix(e->stream, e->S, chain, take, fwd.p, cov.p, out.p, info.p));
+  const size_t o_out = align256(dd * sizeof(double)), o_fwd = o_out + align256(dd * sizeof(double)),
+               o_info = o_fwd + align256((size_t)take * sizeof(int32_t));
+  if ((rc = ensure_stage(e, o_info + 2 * sizeof(int32_t))) != MHX_OK) return rc;
+  double* cov = reinterpret_cast<double*>(e->stage.p);
+  double* out = reinterpret_cast<double*>(e->stage.p + o_out);
+  int32_t* fwd = reinterpret_cast<int32_t*>(e->stage.p + o_fwd);
+  int32_t* info = reinterpret_cast<int32_t*>(e->stage.p + o_info);
+  HIP_TRY(hipMemsetAsync(e->stage.p, 0, o_info + 2 * sizeof(int32_t), e->stream));
+  HIP_TRY(e->fam->l_matrix(e->stream, e->S, chain, take, fwd, cov, out, info));
   HIP_TRY(hipStreamSynchronize(e->stream));
   int32_t hinfo[2];
-  HIP_TRY(hipMemcpy(hinfo, info.p, sizeof hinfo, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(hinfo, info, sizeof hinfo, hipMemcpyDeviceToHost));
   if (status) *status = hinfo[0];
   if (n_forward) *n_forward = hinfo[1];
-  if (L_out) HIP_TRY(hipMemcpy(L_out, out.p, dd * sizeof(double), hipMemcpyDeviceToHost));
+  if (L_out) HIP_TRY(hipMemcpy(L_out, out, dd * sizeof(double), hipMemcpyDeviceToHost));
   return MHX_OK;
 }
 
@@ -1411,6 +1622,38 @@ const char* mhx_kernel_name(mhx_engine* e) {
   return e->kernel_name.c_str();
 }
 
+// ---- native RCCL for one-process-per-GPU hosts -------------------------------------------------
+int mhx_comm_get_unique_id(uint8_t id[128]) {
+  if (!id) return fail(MHX_EINVAL, "id is NULL");
+  Rccl& r = rccl();
+  if (!r.ok) return fail(MHX_ECOMM, "librccl.so could not be loaded");
+  nccl_unique_id u;
+  const int rc = r.GetUniqueId(&u);
+  if (rc != 0) return fail(MHX_ECOMM, "ncclGetUniqueId: %s", r.GetErrorString ? r.GetErrorString(rc) : "error");
+  memcpy(id, u.internal, 128);
+  return MHX_OK;
+}
+
+int mhx_comm_init_rank(mhx_engine* e, const uint8_t id[128], int rank, int n_ranks) {
+  if (!e || !id) return fail(MHX_EINVAL, "NULL argument");
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(MHX_EINVAL, "rank %d of %d", rank, n_ranks);
+  Rccl& r = rccl();
+  if (!r.ok) return fail(MHX_ECOMM, "librccl.so could not be loaded");
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
+  if (e->comm && e->comm_owned) (void)r.CommDestroy(e->comm);
+  e->comm = nullptr;
+  nccl_unique_id u;
+  memcpy(u.internal, id, 128);
+  const int nr = r.CommInitRank(&e->comm, n_ranks, u, rank);
+  if (nr != 0) {
+    e->comm = nullptr;
+    return fail(MHX_ECOMM, "ncclCommInitRank: %s", r.GetErrorString ? r.GetErrorString(nr) : "error");
+  }
+  e->comm_owned = true;
+  return MHX_OK;
+}
+
 int mhx_kernel_timing(mhx_engine* e, int reset, double* avg_ms, uint64_t* launches,
                       double* total_ms) {
   if (!e) return fail(MHX_EINVAL, "engine is NULL");
@@ -1421,6 +1664,297 @@ int mhx_kernel_timing(mhx_engine* e, int reset, double* avg_ms, uint64_t* launch
     e->kernel_ms = 0.0;
     e->timed_launches = 0;
   }
+  return MHX_OK;
+}
+
+
+// ---- several GPUs under ONE host process (the reference's own way of running many walkers is a
+// list mapped in one image, M:1029-1033): one engine + stream per device, contiguous global chain
+// ranges, launches enqueued on every device before any is waited for, and for the pooled
+// covariance ONE ncclAllReduce per tick issued on the engines' streams inside ncclGroupStart/End.
+struct mhx_group {
+  std::vector<mhx_engine*> eng;
+  std::vector<int64_t> first, count;
+  bool rccl_comms = false;    // distinct devices: communicators from ncclCommInitAll
+  DevBuf<double> local_sum;   // same-device groups (tests on one GPU): device-side sum buffer
+  int64_t global_iter = 0;
+};
+
+namespace {
+int group_fail_cleanup(mhx_group* g, int rc) {
+  const std::string keep = g_err;
+  mhx_group_destroy(g);
+  g_err = keep;
+  return rc;
+}
+// the engines of a group that share ONE device cannot use RCCL (a communicator wants distinct
+// devices): their pool vectors are summed by the host through pinned copies.  Only the
+// single-GPU rehearsal of the group code path runs through here.
+int group_pool_sum_local(mhx_group* g) {
+  const mhx_engine* e0 = g->eng[0];
+  const size_t E = 1 + (size_t)e0->P.d + (size_t)e0->P.d * e0->P.d;
+  std::vector<double> sum(E, 0.0), h(E);
+  for (mhx_engine* e : g->eng) {
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(h.data(), e->pool_vec.p, E * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < E; ++i) sum[i] += h[i];  // rank order: reproducible
+  }
+  for (mhx_engine* e : g->eng) {
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpy(e->pool_vec.p, sum.data(), E * sizeof(double), hipMemcpyHostToDevice));
+  }
+  return MHX_OK;
+}
+int group_pool_tick(mhx_group* g) {
+  int rc = MHX_OK;
+  for (mhx_engine* e : g->eng) {
+    HIP_TRY(hipSetDevice(e->device));
+    if ((rc = pool_enqueue_stats(e)) != MHX_OK) return rc;
+  }
+  if (g->eng.size() > 1) {
+    if (g->rccl_comms) {
+      Rccl& r = rccl();
+      if (r.GroupStart() != 0) return fail(MHX_ECOMM, "ncclGroupStart failed");
+      for (mhx_engine* e : g->eng) {
+        HIP_TRY(hipSetDevice(e->device));
+        if ((rc = pool_enqueue_allreduce(e)) != MHX_OK) break;
+      }
+      if (r.GroupEnd() != 0 && rc == MHX_OK) rc = fail(MHX_ECOMM, "ncclGroupEnd failed");
+      if (rc != MHX_OK) return rc;
+    } else if ((rc = group_pool_sum_local(g)) != MHX_OK) {
+      return rc;
+    }
+  }
+  for (mhx_engine* e : g->eng) {
+    HIP_TRY(hipSetDevice(e->device));
+    if ((rc = pool_enqueue_factor(e)) != MHX_OK) return rc;
+  }
+  return MHX_OK;
+}
+}  // namespace
+
+int mhx_group_partition(int64_t n_chains, int n_parts, int part, int64_t* first, int64_t* count) {
+  if (n_chains < 0 || n_parts < 1 || part < 0 || part >= n_parts || !first || !count)
+    return fail(MHX_EINVAL, "mhx_group_partition: bad argument");
+  const int64_t base = n_chains / n_parts, rem = n_chains % n_parts;
+  *count = base + (part < rem ? 1 : 0);
+  *first = base * part + std::min<int64_t>(part, rem);
+  return MHX_OK;
+}
+
+int mhx_group_create(const mhx_config* cfg, const int32_t* devices, int n_devices,
+                     mhx_group** out) {
+  if (!cfg || !devices || !out) return fail(MHX_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (n_devices < 1 || n_devices > 64) return fail(MHX_EINVAL, "n_devices must be in [1,64]");
+  if (cfg->n_chains < n_devices) return fail(MHX_EINVAL, "fewer chains than devices");
+  mhx_group* g = new (std::nothrow) mhx_group();
+  if (!g) return fail(MHX_ENOMEM, "host allocation failed");
+  bool distinct = true;
+  for (int i = 0; i < n_devices; ++i)
+    for (int j = 0; j < i; ++j) distinct = distinct && devices[i] != devices[j];
+  for (int i = 0; i < n_devices; ++i) {
+    mhx_config c = *cfg;
+    int64_t first = 0, count = 0;
+    (void)mhx_group_partition(cfg->n_chains, n_devices, i, &first, &count);
+    c.n_chains = count;
+    c.chain_offset = cfg->chain_offset + first;
+    c.device = devices[i];
+    mhx_engine* e = nullptr;
+    const int rc = mhx_create(&c, &e);
+    if (rc != MHX_OK) return group_fail_cleanup(g, rc);
+    g->eng.push_back(e);
+    g->first.push_back(first);
+    g->count.push_back(count);
+  }
+  if (n_devices > 1 && cfg->adapt_mode == MHX_ADAPT_POOLED && distinct) {
+    Rccl& r = rccl();
+    if (!r.ok) return group_fail_cleanup(g, fail(MHX_ECOMM, "librccl.so could not be loaded"));
+    std::vector<nccl_comm_t> comms((size_t)n_devices, nullptr);
+    std::vector<int> devs(devices, devices + n_devices);
+    const int nr = r.CommInitAll(comms.data(), n_devices, devs.data());
+    if (nr != 0)
+      return group_fail_cleanup(g, fail(MHX_ECOMM, "ncclCommInitAll: %s",
+                                        r.GetErrorString ? r.GetErrorString(nr) : "error"));
+    for (int i = 0; i < n_devices; ++i) {
+      g->eng[(size_t)i]->comm = comms[(size_t)i];
+      g->eng[(size_t)i]->comm_owned = true;
+    }
+    g->rccl_comms = true;
+  }
+  *out = g;
+  return MHX_OK;
+}
+
+void mhx_group_destroy(mhx_group* g) {
+  if (!g) return;
+  for (mhx_engine* e : g->eng) mhx_destroy(e);
+  delete g;
+}
+
+int mhx_group_size(const mhx_group* g) { return g ? (int)g->eng.size() : 0; }
+
+mhx_engine* mhx_group_engine(mhx_group* g, int i) {
+  if (!g || i < 0 || i >= (int)g->eng.size()) {
+    fail(MHX_EINVAL, "group / index");
+    return nullptr;
+  }
+  return g->eng[(size_t)i];
+}
+
+int mhx_group_chain_range(const mhx_group* g, int i, int64_t* first, int64_t* count) {
+  if (!g || i < 0 || i >= (int)g->eng.size()) return fail(MHX_EINVAL, "group / index");
+  if (first) *first = g->first[(size_t)i];
+  if (count) *count = g->count[(size_t)i];
+  return MHX_OK;
+}
+
+#define MHX_GROUP_EACH(call)                       \
+  do {                                             \
+    if (!g) return fail(MHX_EINVAL, "group is NULL"); \
+    for (mhx_engine* e : g->eng) {                 \
+      const int rc_ = (call);                      \
+      if (rc_ != MHX_OK) return rc_;               \
+    }                                              \
+    return MHX_OK;                                 \
+  } while (0)
+
+int mhx_group_set_function(mhx_group* g, int k, int model_id, const int32_t* shape, int n_shape,
+                           const int32_t* param_index, int n_index) {
+  MHX_GROUP_EACH(mhx_set_function(e, k, model_id, shape, n_shape, param_index, n_index));
+}
+int mhx_group_set_dataset(mhx_group* g, int k, const double* x, const double* y,
+                          const double* sigma, size_t n, int likelihood) {
+  MHX_GROUP_EACH(mhx_set_dataset(e, k, x, y, sigma, n, likelihood));  // replicated on every GPU
+}
+int mhx_group_set_bounds(mhx_group* g, int k, const int32_t* idx, const double* lo,
+                         const double* hi, int n) {
+  MHX_GROUP_EACH(mhx_set_bounds(e, k, idx, lo, hi, n));
+}
+int mhx_group_set_function_expr(mhx_group* g, int k, const char* expr,
+                                const char* const* param_names, const int32_t* param_index,
+                                int n_index) {
+  MHX_GROUP_EACH(mhx_set_function_expr(e, k, expr, param_names, param_index, n_index));
+}
+int mhx_group_set_prior_expr(mhx_group* g, int k, const char* expr, const char* const* names,
+                             const int32_t* index, int n) {
+  MHX_GROUP_EACH(mhx_set_prior_expr(e, k, expr, names, index, n));
+}
+int mhx_group_set_likelihood_expr(mhx_group* g, int k, const char* expr) {
+  MHX_GROUP_EACH(mhx_set_likelihood_expr(e, k, expr));
+}
+int mhx_group_request_stop(mhx_group* g) { MHX_GROUP_EACH(mhx_request_stop(e)); }
+
+int mhx_group_init_chains(mhx_group* g, const double* theta0, int broadcast) {
+  if (!g || !theta0) return fail(MHX_EINVAL, "NULL argument");
+  for (size_t i = 0; i < g->eng.size(); ++i) {
+    mhx_engine* e = g->eng[i];
+    const double* th = broadcast ? theta0 : theta0 + (size_t)g->first[i] * (size_t)e->P.d;
+    const int rc = mhx_init_chains(e, th, broadcast);
+    if (rc != MHX_OK) return rc;
+  }
+  return MHX_OK;
+}
+
+int mhx_group_adaptive_begin(mhx_group* g, const mhx_run_opts* o) {
+  if (!g || !o) return fail(MHX_EINVAL, "NULL argument");
+  for (size_t i = 0; i < g->eng.size(); ++i) {
+    mhx_run_opts oi = *o;
+    if (o->l_matrix && o->l_matrix_per_chain)
+      oi.l_matrix = o->l_matrix + (size_t)g->first[i] * (size_t)g->eng[i]->P.d * g->eng[i]->P.d;
+    const int rc = mhx_adaptive_begin(g->eng[i], &oi);
+    if (rc != MHX_OK) return rc;
+  }
+  g->global_iter = 0;
+  return MHX_OK;
+}
+
+int mhx_group_adaptive_advance(mhx_group* g, int64_t max_iters, int64_t* n_running) {
+  if (!g) return fail(MHX_EINVAL, "group is NULL");
+  if (max_iters < 0) return fail(MHX_EINVAL, "max_iters < 0");
+  for (mhx_engine* e : g->eng)
+    if (!e->run_ready) return fail(MHX_ESTATE, "mhx_group_adaptive_begin has not been called");
+  const bool pooled = g->eng[0]->cfg.adapt_mode == MHX_ADAPT_POOLED;
+  int rc = MHX_OK;
+  int64_t left = max_iters;
+  while (left > 0) {
+    const int64_t now = pooled ? std::min<int64_t>(left, 200 - (g->global_iter % 200))
+                               : std::min<int64_t>(left, kTempsWindow);
+    for (mhx_engine* e : g->eng) {  // every GPU gets its launch before any is waited for
+      if ((rc = use_device(e)) != MHX_OK) return rc;
+      if ((rc = launch_steps_enqueue(e, now, 0)) != MHX_OK) return rc;
+    }
+    for (mhx_engine* e : g->eng) {
+      if ((rc = launch_steps_finish(e)) != MHX_OK) return rc;
+      e->global_iter += now;
+    }
+    g->global_iter += now;
+    left -= now;
+    if (pooled && g->global_iter % 200 == 0 && (rc = group_pool_tick(g)) != MHX_OK) return rc;
+    if (left > 0 && (!pooled || g->global_iter % 200 == 0)) {  // "until done": look at the chains
+      int64_t total = 0;
+      for (mhx_engine* e : g->eng) {
+        int64_t r = 0;
+        if ((rc = use_device(e)) != MHX_OK) return rc;
+        if ((rc = count_running(e, &r)) != MHX_OK) return rc;
+        total += r;
+      }
+      if (total == 0) break;
+    }
+  }
+  if (n_running) {
+    int64_t total = 0;
+    for (mhx_engine* e : g->eng) {
+      int64_t r = 0;
+      if ((rc = use_device(e)) != MHX_OK) return rc;
+      if ((rc = count_running(e, &r)) != MHX_OK) return rc;
+      total += r;
+    }
+    *n_running = total;
+  }
+  return MHX_OK;
+}
+
+int mhx_group_adaptive_steps_full(mhx_group* g, const mhx_run_opts* o) {
+  int rc = mhx_group_adaptive_begin(g, o);
+  if (rc != MHX_OK) return rc;
+  int64_t running = 1;
+  while (running > 0) {
+    int64_t chunk = 1 << 16;
+    for (mhx_engine* e : g->eng) chunk = std::min(chunk, e->chunk_iters);
+    if ((rc = mhx_group_adaptive_advance(g, chunk, &running)) != MHX_OK) return rc;
+  }
+  return MHX_OK;
+}
+
+int mhx_group_get_state(mhx_group* g, double* theta, double* logpost, double* best_theta,
+                        double* best_logpost, int64_t* length, int64_t* age) {
+  if (!g) return fail(MHX_EINVAL, "group is NULL");
+  for (size_t i = 0; i < g->eng.size(); ++i) {
+    mhx_engine* e = g->eng[i];
+    const size_t f = (size_t)g->first[i], d = (size_t)e->P.d;
+    const int rc = mhx_get_state(e, theta ? theta + f * d : nullptr, logpost ? logpost + f : nullptr,
+                                 best_theta ? best_theta + f * d : nullptr,
+                                 best_logpost ? best_logpost + f : nullptr,
+                                 length ? length + f : nullptr, age ? age + f : nullptr);
+    if (rc != MHX_OK) return rc;
+  }
+  return MHX_OK;
+}
+
+int mhx_group_get_counters(mhx_group* g, uint64_t* chain_steps, uint64_t* kernel_launches) {
+  if (!g) return fail(MHX_EINVAL, "group is NULL");
+  uint64_t cs = 0, kl = 0;
+  for (mhx_engine* e : g->eng) {
+    uint64_t a = 0, b = 0;
+    const int rc = mhx_get_counters(e, &a, &b);
+    if (rc != MHX_OK) return rc;
+    cs += a;
+    kl += b;
+  }
+  if (chain_steps) *chain_steps = cs;
+  if (kernel_launches) *kernel_launches = kl;
   return MHX_OK;
 }
 

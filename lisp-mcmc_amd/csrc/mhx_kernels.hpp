@@ -1172,7 +1172,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     }
     const int64_t i = r.loop_i;
     // annealing M:920-921
-    if (!r.shutting && i < R.temp_steps) r.T = uniform_f64(R.temps[i]);
+    if (!r.shutting && i < R.temp_steps) r.T = uniform_f64(R.temps[i - R.temps_first]);
     // cleaning M:923-927 (:keep-walks only shortens what :take can see)
     if (R.has_mwl && i == r.reset_index) {
       if (r.length > R.mwl) {

@@ -109,7 +109,8 @@ struct ChainState {
 struct RunDesc {
   int64_t n, sts, temp_steps, mwl, tail;
   int32_t auto_mode, has_mwl, adapt_mode;
-  const double* temps;  // [temp_steps]
+  const double* temps;  // entries [temps_first, temps_first + window) of the schedule: the host
+  int64_t temps_first;  // keeps the window over the loop indices of the launch (mhx_engine.cpp)
   const int32_t* stop_flag;
 };
 

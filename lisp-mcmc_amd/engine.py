@@ -146,8 +146,20 @@ class Engine:
         capi.check(capi.lib().mhx_many_steps(self._h, int(n), La.ctypes.data_as(capi.f64p),
                                              1 if La.ndim == 3 else 0))
 
+    def take_step(self, L, temperature=1.0):
+        """(walker-take-step w :l-matrix L :temperature T) for every chain, device randomness"""
+        La = np.ascontiguousarray(L, dtype=np.float64)
+        capi.check(capi.lib().mhx_take_step(self._h, La.ctypes.data_as(capi.f64p),
+                                            1 if La.ndim == 3 else 0, float(temperature)))
+
     def request_stop(self):
         capi.check(capi.lib().mhx_request_stop(self._h))
+
+    def comm_init_rank(self, unique_id, rank, n_ranks):
+        """join the RCCL communicator of a one-process-per-GPU job (collective); unique_id: the
+        128 bytes rank 0 got from comm_unique_id()"""
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        capi.check(capi.lib().mhx_comm_init_rank(self._h, buf, int(rank), int(n_ranks)))
 
     def set_allreduce(self, fn, device_buffer=False):
         """fn(ptr, n, device_buffer) -> 0; sums n doubles at ptr over all ranks in place."""
@@ -177,6 +189,18 @@ class Engine:
             bt.ctypes.data_as(capi.f64p), bl.ctypes.data_as(capi.f64p),
             ln.ctypes.data_as(capi.i64p), ag.ctypes.data_as(capi.i64p)))
         return dict(theta=th, logpost=lp, best_theta=bt, best_logpost=bl, length=ln, age=ag)
+
+    def chain(self, c):
+        """one chain's state (mhx_get_chain): what the accessors of one walker read"""
+        d = self.d
+        th, bt = np.zeros(d), np.zeros(d)
+        lp, bl = C.c_double(0), C.c_double(0)
+        ln, ag = C.c_int64(0), C.c_int64(0)
+        capi.check(capi.lib().mhx_get_chain(
+            self._h, int(c), th.ctypes.data_as(capi.f64p), C.byref(lp),
+            bt.ctypes.data_as(capi.f64p), C.byref(bl), C.byref(ln), C.byref(ag)))
+        return dict(theta=th, logpost=lp.value, best_theta=bt, best_logpost=bl.value,
+                    length=ln.value, age=ag.value)
 
     def chain_status(self):
         st = np.zeros(self.n_chains, dtype=np.int32)
@@ -256,3 +280,128 @@ class Engine:
         capi.check(capi.lib().mhx_kernel_timing(self._h, int(reset), C.byref(avg), C.byref(n),
                                                 C.byref(tot)))
         return dict(avg_ms=avg.value, launches=n.value, total_ms=tot.value)
+
+
+def comm_unique_id():
+    """128 bytes identifying a new RCCL communicator (rank 0 calls this and passes them on)"""
+    buf = (C.c_uint8 * 128)()
+    capi.check(capi.lib().mhx_comm_get_unique_id(buf))
+    return bytes(buf)
+
+
+def partition(n_chains, n_parts, part):
+    """(first, count) of part's contiguous chain range (mhx_group_partition; no device needed)"""
+    a, b = C.c_int64(0), C.c_int64(0)
+    capi.check(capi.lib().mhx_group_partition(int(n_chains), int(n_parts), int(part),
+                                              C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+class _GroupEngine(Engine):
+    """engine i of a group, seen through the per-engine entry points (owned by the group)"""
+
+    def __init__(self, handle, n_chains, d, K):  # noqa: super().__init__ creates; this borrows
+        self._h = C.c_void_p(handle)
+        self._cb = None
+        self.n_chains, self.d, self.K = int(n_chains), int(d), int(K)
+
+    def close(self):
+        self._h = C.c_void_p()
+
+
+class Group:
+    """ONE host process, several GPUs (include/mhx.h, mhx_group_*): n_chains walkers in all,
+    contiguous global id ranges per device, launches enqueued on every device before any is
+    waited for, the pooled tick's all-reduce through RCCL."""
+
+    def __init__(self, n_chains, n_params, n_functions=1, devices=(0,), seed=0, chain_offset=0,
+                 adapt_mode=capi.ADAPT_FAITHFUL, history_capacity=0, poisson_logfact_double=False):
+        cfg = capi.Config()
+        cfg.n_chains, cfg.n_params, cfg.n_functions = int(n_chains), int(n_params), int(n_functions)
+        cfg.adapt_mode, cfg.seed = int(adapt_mode), int(seed)
+        cfg.chain_offset, cfg.history_capacity = int(chain_offset), int(history_capacity)
+        cfg.poisson_logfact_double = int(bool(poisson_logfact_double))
+        self.n_chains, self.d, self.K = int(n_chains), int(n_params), int(n_functions)
+        dev, devp = capi.as_i32(list(devices))
+        self._h = C.c_void_p()
+        capi.check(capi.lib().mhx_group_create(C.byref(cfg), devp, len(dev), C.byref(self._h)))
+        self.ranges = []
+        self.engines = []
+        for i in range(capi.lib().mhx_group_size(self._h)):
+            a, b = C.c_int64(0), C.c_int64(0)
+            capi.check(capi.lib().mhx_group_chain_range(self._h, i, C.byref(a), C.byref(b)))
+            self.ranges.append((a.value, b.value))
+            self.engines.append(_GroupEngine(capi.lib().mhx_group_engine(self._h, i), b.value,
+                                             self.d, self.K))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            for e in self.engines:
+                e.close()
+            capi.lib().mhx_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # problem definition: the same calls as Engine, applied to every device
+    def set_function(self, k, model, shape=(), param_index=()):
+        sh, shp = capi.as_i32(list(shape) if len(shape) else [0])
+        ix, ixp = capi.as_i32(list(param_index))
+        capi.check(capi.lib().mhx_group_set_function(self._h, k, model, shp, len(shape), ixp, len(ix)))
+
+    def set_dataset(self, k, x, y, sigma=None, likelihood=capi.LIK_NORMAL):
+        xa, xp = capi.as_f64(x)
+        ya, yp = capi.as_f64(y)
+        sp = None
+        if sigma is not None:
+            sa, sp = capi.as_f64(np.broadcast_to(np.asarray(sigma, dtype=np.float64), xa.shape))
+        capi.check(capi.lib().mhx_group_set_dataset(self._h, k, xp, yp, sp, xa.size, likelihood))
+
+    def set_bounds(self, k, idx, lo, hi):
+        ix, ixp = capi.as_i32(list(idx))
+        la, lp = capi.as_f64(lo)
+        ha, hp = capi.as_f64(hi)
+        capi.check(capi.lib().mhx_group_set_bounds(self._h, k, ixp, lp, hp, len(ix)))
+
+    def init_chains(self, theta0):
+        th = np.ascontiguousarray(theta0, dtype=np.float64)
+        bc = 1 if th.ndim == 1 else 0
+        capi.check(capi.lib().mhx_group_init_chains(self._h, th.ctypes.data_as(capi.f64p), bc))
+
+    def adaptive_begin(self, n=100000, temperature=1e3, auto=1, max_walker_length=0, l_matrix=None):
+        o = Engine._opts(self, n, temperature, auto, max_walker_length, l_matrix)
+        capi.check(capi.lib().mhx_group_adaptive_begin(self._h, C.byref(o)))
+
+    def adaptive_advance(self, max_iters, count=True):
+        n = C.c_int64(-1)
+        capi.check(capi.lib().mhx_group_adaptive_advance(self._h, int(max_iters),
+                                                         C.byref(n) if count else None))
+        return n.value
+
+    def adaptive_steps_full(self, n=100000, temperature=1e3, auto=1, max_walker_length=0,
+                            l_matrix=None):
+        o = Engine._opts(self, n, temperature, auto, max_walker_length, l_matrix)
+        capi.check(capi.lib().mhx_group_adaptive_steps_full(self._h, C.byref(o)))
+
+    def request_stop(self):
+        capi.check(capi.lib().mhx_group_request_stop(self._h))
+
+    def state(self):
+        C_, d = self.n_chains, self.d
+        th, bt = np.zeros((C_, d)), np.zeros((C_, d))
+        lp, bl = np.zeros(C_), np.zeros(C_)
+        ln, ag = np.zeros(C_, dtype=np.int64), np.zeros(C_, dtype=np.int64)
+        capi.check(capi.lib().mhx_group_get_state(
+            self._h, th.ctypes.data_as(capi.f64p), lp.ctypes.data_as(capi.f64p),
+            bt.ctypes.data_as(capi.f64p), bl.ctypes.data_as(capi.f64p),
+            ln.ctypes.data_as(capi.i64p), ag.ctypes.data_as(capi.i64p)))
+        return dict(theta=th, logpost=lp, best_theta=bt, best_logpost=bl, length=ln, age=ag)
+
+    def counters(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        capi.check(capi.lib().mhx_group_get_counters(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value

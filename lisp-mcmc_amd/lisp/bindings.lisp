@@ -108,6 +108,52 @@ library, or without a gfx950 device, walker-create signals MHX-ERROR."
 (cffi:defcfun ("mhx_kernel_timing" %mhx-kernel-timing) :int
   (e :pointer) (reset :int) (avg-ms :pointer) (launches :pointer) (total-ms :pointer))
 
+(cffi:defcfun ("mhx_take_step" %mhx-take-step) :int
+  (e :pointer) (l :pointer) (per-chain-l :int) (temperature :double))
+(cffi:defcfun ("mhx_get_chain" %mhx-get-chain) :int
+  (e :pointer) (chain :int64) (theta :pointer) (logpost :pointer) (best-theta :pointer)
+  (best-logpost :pointer) (length :pointer) (age :pointer))
+;;; native RCCL for one-process-per-GPU hosts (a Lisp image per GPU, e.g. under MPI)
+(cffi:defcfun ("mhx_comm_get_unique_id" %mhx-comm-get-unique-id) :int (id :pointer))
+(cffi:defcfun ("mhx_comm_init_rank" %mhx-comm-init-rank) :int
+  (e :pointer) (id :pointer) (rank :int) (n-ranks :int))
+;;; one Lisp image, several GPUs
+(cffi:defcfun ("mhx_group_partition" %mhx-group-partition) :int
+  (n-chains :int64) (n-parts :int) (part :int) (first :pointer) (count :pointer))
+(cffi:defcfun ("mhx_group_create" %mhx-group-create) :int
+  (cfg :pointer) (devices :pointer) (n-devices :int) (out :pointer))
+(cffi:defcfun ("mhx_group_destroy" %mhx-group-destroy) :void (g :pointer))
+(cffi:defcfun ("mhx_group_size" %mhx-group-size) :int (g :pointer))
+(cffi:defcfun ("mhx_group_engine" %mhx-group-engine) :pointer (g :pointer) (i :int))
+(cffi:defcfun ("mhx_group_chain_range" %mhx-group-chain-range) :int
+  (g :pointer) (i :int) (first :pointer) (count :pointer))
+(cffi:defcfun ("mhx_group_set_function" %mhx-group-set-function) :int
+  (g :pointer) (k :int) (model-id :int) (shape :pointer) (n-shape :int)
+  (param-index :pointer) (n-index :int))
+(cffi:defcfun ("mhx_group_set_dataset" %mhx-group-set-dataset) :int
+  (g :pointer) (k :int) (x :pointer) (y :pointer) (sigma :pointer) (n :size) (likelihood :int))
+(cffi:defcfun ("mhx_group_set_bounds" %mhx-group-set-bounds) :int
+  (g :pointer) (k :int) (idx :pointer) (lo :pointer) (hi :pointer) (n :int))
+(cffi:defcfun ("mhx_group_set_function_expr" %mhx-group-set-function-expr) :int
+  (g :pointer) (k :int) (expr :string) (param-names :pointer) (param-index :pointer) (n-index :int))
+(cffi:defcfun ("mhx_group_set_prior_expr" %mhx-group-set-prior-expr) :int
+  (g :pointer) (k :int) (expr :string) (names :pointer) (index :pointer) (n :int))
+(cffi:defcfun ("mhx_group_set_likelihood_expr" %mhx-group-set-likelihood-expr) :int
+  (g :pointer) (k :int) (expr :string))
+(cffi:defcfun ("mhx_group_init_chains" %mhx-group-init-chains) :int
+  (g :pointer) (theta0 :pointer) (broadcast :int))
+(cffi:defcfun ("mhx_group_adaptive_begin" %mhx-group-adaptive-begin) :int (g :pointer) (o :pointer))
+(cffi:defcfun ("mhx_group_adaptive_advance" %mhx-group-adaptive-advance) :int
+  (g :pointer) (max-iters :int64) (n-running :pointer))
+(cffi:defcfun ("mhx_group_adaptive_steps_full" %mhx-group-adaptive-steps-full) :int
+  (g :pointer) (o :pointer))
+(cffi:defcfun ("mhx_group_request_stop" %mhx-group-request-stop) :int (g :pointer))
+(cffi:defcfun ("mhx_group_get_state" %mhx-group-get-state) :int
+  (g :pointer) (theta :pointer) (logpost :pointer) (best-theta :pointer) (best-logpost :pointer)
+  (length :pointer) (age :pointer))
+(cffi:defcfun ("mhx_group_get_counters" %mhx-group-get-counters) :int
+  (g :pointer) (chain-steps :pointer) (kernel-launches :pointer))
+
 (defmacro with-c-call (&body body)
   "HIP/RCCL runtime code may raise inexact/invalid flags that SBCL turns into conditions;
 mask the traps around every foreign call (SURVEY 8b)."

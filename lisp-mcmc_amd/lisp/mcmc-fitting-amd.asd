@@ -4,7 +4,7 @@
 ;;;; (include/mhx.h) in hand-written gfx950 kernels.
 (asdf:defsystem #:mcmc-fitting-amd
   :description "MI355X-native drop-in for the walker-adaptive-steps path of afranson/Lisp-MCMC"
-  :version "0.1.0"
+  :version "0.2.0"
   :license "MIT"
   :depends-on (#:cffi)
   :serial t

@@ -15,7 +15,8 @@
    #:walker-step #:make-walker-step #:walker-step-prob #:walker-step-params
    #:walker-create #:mcmc-fit
    #:walker-adaptive-steps #:walker-adaptive-steps-full #:walker-many-steps
-   #:walker-take-step #:walker-get #:walker-modify #:walker-destroy
+   #:walker-take-step #:walker-take-step-injected #:walker-get #:walker-modify #:walker-destroy
+   #:walker-save #:walker-load #:diagonal-covariance
    #:mfit-walker-estop #:request-stop
    ;; likelihood / prior designators
    #:log-liklihood-normal #:log-liklihood-normal-weighted #:log-liklihood-normal-cutoff

@@ -2,7 +2,7 @@
 commented-out code sketches (mcmc-fitting.lisp:971-1001):
 
     (:FN names :DATA data :PARAM-KEYS keys :STDDEV stddev :LOG-LIKLIHOOD names
-     :LOG-PRIOR names :WALKER (#S(WALKER-STEP :PROB p :PARAMS (:k v ...)) ...))
+     :LOG-PRIOR names :WALKER ((:PROB p :PARAMS (:k v ...)) ...))
 
 written with the Lisp printer's conventions (`with-standard-io-syntax`: upper-case symbols,
 doubles with a d exponent) so that a Lisp `read` takes the file as is.  Functions are not
@@ -58,7 +58,7 @@ def walker_save(walker, filename, take=None, chain=0):
            " :WALKER ("]
     for s in steps:
         plist = " ".join(":%s %s" % (k.upper().replace("_", "-"), _d(s.params[k])) for k in keys)
-        out.append("  #S(WALKER-STEP :PROB %s :PARAMS (%s))" % (_d(s.prob), plist))
+        out.append("  (:PROB %s :PARAMS (%s))" % (_d(s.prob), plist))
     out.append(" ))")
     with open(filename, "w") as f:
         f.write("\n".join(out) + "\n")
@@ -83,8 +83,9 @@ def read_saved(filename):
     keys = [sexpr.mangle(k) for k in _getf(form, ":PARAM-KEYS")]
     steps = []
     for st in _getf(form, ":WALKER"):
-        # (WALKER-STEP :PROB p :PARAMS (...))
-        body = st[1:]
+        # (:PROB p :PARAMS (...)), what the Lisp shim's walker-save writes too; files of
+        # round 1 have #S(WALKER-STEP :PROB p :PARAMS (...))
+        body = st if str(st[0]).startswith(":") else st[1:]
         prob = _num(_getf(body, ":PROB"))
         pl = _getf(body, ":PARAMS")
         vals = {sexpr.mangle(pl[i]): _num(pl[i + 1]) for i in range(0, len(pl), 2)}

@@ -319,12 +319,19 @@ def walker_many_steps(walker, n, l_matrix=None):
 
 def walker_take_step(walker, l_matrix=None, temperature=1, z=None, u=None, rng=None):
     """(walker-take-step walker &key l-matrix (temperature 1)) M:1072-1095.  z / u are the
-    numbers alexandria:gaussian-random (M:687) and (random 1.0d0) (M:1092) would return;
-    when omitted they come from a host generator (the reference's stream is unseeded)."""
+    numbers alexandria:gaussian-random (M:687) and (random 1.0d0) (M:1092) would return
+    (the parity hook, mhx_step_injected); when all are omitted the device draws its own
+    (mhx_take_step), as the reference does."""
     e = walker.engine
     if l_matrix is None:  # M:1074
         ml = walker_get(walker, get=":most-likely-params", take=1000)
         l_matrix = np.diag([float(np.float32(1e-2)) * v for v in ml.values()])
+    if z is None and u is None and rng is None:
+        # the reference draws its own randomness (M:687, M:1092): so does the device (Philox,
+        # the chain's next draw) - mhx_take_step
+        e.take_step(l_matrix, temperature)
+        walker._raise_on_trap()
+        return None
     rng = rng or np.random.default_rng()
     if z is None:
         z = rng.standard_normal((e.n_chains, e.d))

@@ -26,7 +26,7 @@ def test_library_exports_every_header_symbol():
         assert hasattr(lib, n), n
         assert n in capi.SIGNATURES, "ctypes table misses %s" % n
     assert sorted(capi.SIGNATURES) == names
-    assert lib.mhx_version() == 100
+    assert lib.mhx_version() == 200
 
 
 def test_no_cpu_fallback_without_device():
