@@ -10,7 +10,8 @@ falls inside the timed region).  Inputs are resident in HBM before the timed reg
 
 N > 1: launched by torch.distributed.run, one rank per GPU; chains are sharded by contiguous
 global id ranges (weak scaling: --chains per GPU), no data-path collective in the reference's
-per-walker adaptation mode.
+per-walker adaptation mode; the pooled-covariance mode (default for N > 1) adds ONE RCCL
+all-reduce of 1+d+d^2 doubles per 200 iterations, issued by libmhx itself on the engine's stream.
 """
 import argparse
 import json
@@ -201,9 +202,13 @@ def main():
         desc += " [model compiled at run time from its Lisp closure text]"
     if pooled and dist is not None:
         # the one exchange step of the path: 1+d+d^2 doubles summed over ranks every 200
-        # iterations, RCCL over xGMI directly on the engine's device buffer
-        from lisp_mcmc_amd import distributed as mdist
-        e.set_allreduce(mdist.torch_allreduce_hook(dist), device_buffer=True)
+        # iterations by libmhx's OWN RCCL communicator (mhx_comm_init_rank): ncclAllReduce on the
+        # engine's stream between the statistics kernels and the factorisation, no host
+        # synchronisation, no Python in the data path.  torch.distributed only carries the 128-byte
+        # communicator id from rank 0 to the others (and the barriers / max of the contract).
+        uid = [mhx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        e.comm_init_rank(uid[0], rank, world)
     # per-chain start: theta* (1 + 0.01 N(0,1)), keyed by GLOBAL chain id
     rng = np.random.Generator(np.random.Philox(key=0x5EED0002 + rank))
     th0 = spec.theta_star[None, :] * (1.0 + 0.01 * rng.standard_normal((chains, spec.d)))

@@ -53,6 +53,13 @@ extern __shared__ __attribute__((aligned(16))) unsigned char mhx_lds_raw[];
 typedef __attribute__((address_space(3))) const double* lds_cdptr_t;
 typedef double mhx_double2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const mhx_double2* lds_cd2ptr_t;
+// an LDS address whose relation to other addresses the optimiser may not use (see sweep())
+__device__ __forceinline__ lds_cdptr_t opaque_lds(lds_cdptr_t p) {
+#ifndef MHX_FUSED_LDS_READS  // (build knob for A/B measurements: tools/ab_build.sh)
+  asm volatile("" : "+v"(p));
+#endif
+  return p;
+}
 __device__ __forceinline__ lds_cdptr_t lds_logtab() {
   return (lds_cdptr_t)reinterpret_cast<LdsHead*>(mhx_lds_raw)->logtab;
 }
@@ -411,136 +418,7 @@ __device__ __forceinline__ double mlog(double x) {
 // instructions + one ds_read_b128, where mlog() needs 42.  Arguments within 1/16 of 1 - where
 // the table terms cancel - and everything mlog() answers with NaN go through mlog().
 __device__ const double kLogTab[128][2] = {
-// generated by tools/gen_log_table.py: {1/c_i, log c_i}, log c_i a multiple of 2^-43 and
-// within 3.3e-21 of the true logarithm of c_i
-    {0x1.734f0c6c60682p+0, -0x1.7cc7f81e28800p-2},
-    {0x1.713786d20870cp+0, -0x1.76feeca3ca800p-2},
-    {0x1.6f26013a64b7bp+0, -0x1.713e331147000p-2},
-    {0x1.6d1a626b504ffp+0, -0x1.6b85b4d8f5800p-2},
-    {0x1.6b14908db0388p+0, -0x1.65d5588469000p-2},
-    {0x1.691473acb4524p+0, -0x1.602d08bad0800p-2},
-    {0x1.6719f35b1c3d0p+0, -0x1.5a8cadadbc800p-2},
-    {0x1.6524f83176e55p+0, -0x1.54f4315591000p-2},
-    {0x1.63356b8dee4ecp+0, -0x1.4f637ecad2800p-2},
-    {0x1.614b36a5c27fbp+0, -0x1.49da7fa03e000p-2},
-    {0x1.5f6643644003fp+0, -0x1.44591e675c800p-2},
-    {0x1.5d867c2fdf3a1p+0, -0x1.3edf461056800p-2},
-    {0x1.5babcc746400fp+0, -0x1.396ce3888a800p-2},
-    {0x1.59d61f1c77d16p+0, -0x1.3401e14937800p-2},
-    {0x1.58055ffbdbd4ep+0, -0x1.2e9e2b81be800p-2},
-    {0x1.56397bc013a53p+0, -0x1.2941affa41800p-2},
-    {0x1.54725e8af2d1fp+0, -0x1.23ec59efda000p-2},
-    {0x1.52aff56c888f2p+0, -0x1.1e9e167eae800p-2},
-    {0x1.50f22e0d957ddp+0, -0x1.1956d3af04800p-2},
-    {0x1.4f38f661eea8ep+0, -0x1.14167f928e800p-2},
-    {0x1.4d843bdf2bf59p+0, -0x1.0edd05dead000p-2},
-    {0x1.4bd3edf2dbe46p+0, -0x1.09aa5779df000p-2},
-    {0x1.4a27fad6105e5p+0, -0x1.047e60c9d7000p-2},
-    {0x1.4880523452352p+0, -0x1.feb223bcd1000p-3},
-    {0x1.46dce35718e05p+0, -0x1.f474b1a297000p-3},
-    {0x1.453d9e3b89942p+0, -0x1.ea444a4f31000p-3},
-    {0x1.43a27311d3f6ap+0, -0x1.e020cc8f07000p-3},
-    {0x1.420b525d429f9p+0, -0x1.d60a17c217000p-3},
-    {0x1.40782d1357fa3p+0, -0x1.cc000cad52000p-3},
-    {0x1.3ee8f42905333p+0, -0x1.c2028aa8ed000p-3},
-    {0x1.3d5d99106ae35p+0, -0x1.b81172c974000p-3},
-    {0x1.3bd60da6f67a9p+0, -0x1.ae2ca77d19000p-3},
-    {0x1.3a52438c86572p+0, -0x1.a454084e06000p-3},
-    {0x1.38d22d25f5d24p+0, -0x1.9a87787340000p-3},
-    {0x1.3755bd0b7fe0cp+0, -0x1.90c6db2f71000p-3},
-    {0x1.35dce60720706p+0, -0x1.871213cc29000p-3},
-    {0x1.34679ac8800c8p+0, -0x1.7d6903a668000p-3},
-    {0x1.32f5ceeae7db5p+0, -0x1.73cb90fc40000p-3},
-    {0x1.31877599b395cp+0, -0x1.6a399df605000p-3},
-    {0x1.301c82ae1efe5p+0, -0x1.60b31017a2000p-3},
-    {0x1.2eb4ea1564fb0p+0, -0x1.5737cc48d8000p-3},
-    {0x1.2d50a0172687ep+0, -0x1.4dc7b8b516000p-3},
-    {0x1.2bef9905bd092p+0, -0x1.4462bab7ca000p-3},
-    {0x1.2a91c942f6ca9p+0, -0x1.3b08b6fcd4000p-3},
-    {0x1.293725bfd08c7p+0, -0x1.31b994f15e000p-3},
-    {0x1.27dfa3ad40c30p+0, -0x1.28753cb457000p-3},
-    {0x1.268b37b7865a5p+0, -0x1.1f3b91c738000p-3},
-    {0x1.2539d7f13d5aap+0, -0x1.160c805d9b000p-3},
-    {0x1.23eb797475497p+0, -0x1.0ce7ecf1d3000p-3},
-    {0x1.22a0122d930cfp+0, -0x1.03cdc0be47000p-3},
-    {0x1.215797fb0c1fdp+0, -0x1.f57bc752e4000p-4},
-    {0x1.2012012537a9fp+0, -0x1.e3707f2c34000p-4},
-    {0x1.1ecf43e72db5ap+0, -0x1.d1797a3f9e000p-4},
-    {0x1.1d8f568f63830p+0, -0x1.bf968902b8000p-4},
-    {0x1.1c522fba7235dp+0, -0x1.adc77e7bac000p-4},
-    {0x1.1b17c6755c973p+0, -0x1.9c0c3246e6000p-4},
-    {0x1.19e011941325dp+0, -0x1.8a647718d4000p-4},
-    {0x1.18ab0844ea9bep+0, -0x1.78d0231198000p-4},
-    {0x1.1778a1b5864d0p+0, -0x1.674f0a9fde000p-4},
-    {0x1.1648d55bad3bdp+0, -0x1.55e104ae3e000p-4},
-    {0x1.151b9a2a467f0p+0, -0x1.4485defea0000p-4},
-    {0x1.13f0e8f7abcaep+0, -0x1.333d819de2000p-4},
-    {0x1.12c8b89b7821bp+0, -0x1.2207b594fc000p-4},
-    {0x1.11a3019e6afd2p+0, -0x1.10e45b7800000p-4},
-    {0x1.107fbbee0d442p+0, -0x1.ffa692bf28000p-5},
-    {0x1.0f5edfb6979f6p+0, -0x1.dda8af1e80000p-5},
-    {0x1.0e4065545ea39p+0, -0x1.bbcebf5404000p-5},
-    {0x1.0d24456ae2e4fp+0, -0x1.9a187c3c98000p-5},
-    {0x1.0c0a787375f07p+0, -0x1.788596ec1c000p-5},
-    {0x1.0af2f743d8ff0p+0, -0x1.5715c8b250000p-5},
-    {0x1.09ddba4d1bf14p+0, -0x1.35c8bc1200000p-5},
-    {0x1.08cabb33f25eep+0, -0x1.149e3dd720000p-5},
-    {0x1.07b9f2b1b74b2p+0, -0x1.e72bf7e1d8000p-6},
-    {0x1.06ab59b7b1912p+0, -0x1.a55f50ae40000p-6},
-    {0x1.059ee9dac90eep+0, -0x1.63d60cac00000p-6},
-    {0x1.04949ccd0d506p+0, -0x1.228fb4db48000p-6},
-    {0x1.038c6b5856e44p+0, -0x1.c317289d50000p-7},
-    {0x1.02864fb3fa6bbp+0, -0x1.419295f2c0000p-7},
-    {0x1.0182434df102dp+0, -0x1.81210a41a0000p-8},
-    {0x1.00804011aaa91p+0, -0x1.003ff8a100000p-9},
-    {0x1.fe01fdeef45c6p-1, 0x1.ff00bd47c0000p-9},
-    {0x1.fa11ca7304754p-1, 0x1.7dc48160b0000p-7},
-    {0x1.f6310acfbed88p-1, 0x1.3cea437ab8000p-6},
-    {0x1.f25f643f59d40p-1, 0x1.b9fc02d850000p-6},
-    {0x1.ee9c7f7026fabp-1, 0x1.1b0d99e0b8000p-5},
-    {0x1.eae807a7f877bp-1, 0x1.58a5bb398c000p-5},
-    {0x1.e741aa5665b98p-1, 0x1.95c8312000000p-5},
-    {0x1.e3a91790ef09cp-1, 0x1.d276b986e0000p-5},
-    {0x1.e01e01ed13b99p-1, 0x1.075982eafe000p-4},
-    {0x1.dca01dc30ada0p-1, 0x1.253f632c7c000p-4},
-    {0x1.d92f2244cbd56p-1, 0x1.42edcb46e0000p-4},
-    {0x1.d5cac81595396p-1, 0x1.60658a1748000p-4},
-    {0x1.d272ca18356dep-1, 0x1.7da768331c000p-4},
-    {0x1.cf26e5f09ee53p-1, 0x1.9ab422da06000p-4},
-    {0x1.cbe6d99b5a5e9p-1, 0x1.b78c80ab72000p-4},
-    {0x1.c8b265b30c2d4p-1, 0x1.d4313d48f6000p-4},
-    {0x1.c5894d1cb67efp-1, 0x1.f0a30b95c6000p-4},
-    {0x1.c26b538e10679p-1, 0x1.06715142b3000p-3},
-    {0x1.bf583eeece73fp-1, 0x1.147858292b000p-3},
-    {0x1.bc4fd66909b13p-1, 0x1.2266f1447d000p-3},
-    {0x1.b951e2ad726c0p-1, 0x1.303d71a161000p-3},
-    {0x1.b65e2e641433fp-1, 0x1.3dfc2a533e000p-3},
-    {0x1.b37484cdc0141p-1, 0x1.4ba36ea1fa000p-3},
-    {0x1.b094b32e61975p-1, 0x1.59338d49ec000p-3},
-    {0x1.adbe87f5bc9b8p-1, 0x1.66acd43814000p-3},
-    {0x1.aaf1d3099c3e3p-1, 0x1.740f8f01ea000p-3},
-    {0x1.a82e650efcc9ep-1, 0x1.815c0a27d9000p-3},
-    {0x1.a574107ac72adp-1, 0x1.8e928dd3e7000p-3},
-    {0x1.a2c2a88d0d3bcp-1, 0x1.9bb362960b000p-3},
-    {0x1.a01a019cb1f83p-1, 0x1.a8becfd947000p-3},
-    {0x1.9d79f18435fa0p-1, 0x1.b5b519a620000p-3},
-    {0x1.9ae24eb9de00dp-1, 0x1.c29684f253000p-3},
-    {0x1.9852f0bbd7667p-1, 0x1.cf63557278000p-3},
-    {0x1.95cbb0e3135fep-1, 0x1.dc1bc950b9000p-3},
-    {0x1.934c67f45a83fp-1, 0x1.e8c02545ca000p-3},
-    {0x1.90d4f11d2552ep-1, 0x1.f550a573cd000p-3},
-    {0x1.8e65279cb070cp-1, 0x1.00e6c48a17800p-2},
-    {0x1.8bfce7d54a147p-1, 0x1.071b867b48000p-2},
-    {0x1.899c0f4a20d91p-1, 0x1.0d46b5b2d2000p-2},
-    {0x1.87427bc7638d0p-1, 0x1.1368703564000p-2},
-    {0x1.84f00c78a8886p-1, 0x1.1980d20796800p-2},
-    {0x1.82a4a01b2a5bdp-1, 0x1.1f8ff9dc98000p-2},
-    {0x1.806017feafd15p-1, 0x1.2596012177000p-2},
-    {0x1.7e225518283c9p-1, 0x1.2b9303a4ce000p-2},
-    {0x1.7beb390c2996cp-1, 0x1.31871cd27c000p-2},
-    {0x1.79baa6ad239adp-1, 0x1.377266529f000p-2},
-    {0x1.77908115fd694p-1, 0x1.3d54fa662a800p-2},
-    {0x1.756cac1d7dd05p-1, 0x1.432ef2a76f800p-2},
+#include "mhx_log_table.inc"
 };
 // a3: the constant 1/5 of the polynomial handed in from a VGPR the caller keeps alive across its
 // loop (tlog_a3()): fma(r, A4, A3) reads two constants and only one may come from the scalar
@@ -659,6 +537,11 @@ struct PeaksModel {
     // one point of a lane to its next (64 grid points on); rec: usable this step
     double rm2d[NPK], rnd2[NPK], rq[NPK];
     unsigned rmask;  // bit k: peak k goes by the recurrence this step
+    // ... and when EVERY peak does, so does a constant or linear background (b(x + 64 h) =
+    // b(x) + 64 h b1, re-seeded with the peaks): such a step never reads x beyond the seeds, which
+    // takes a third off the LDS traffic of the sweep.  Decided per step, not per tile.
+    double bgH;
+    bool bgrec;
   };
   // ---- Gaussians on a uniformly spaced x grid: a two-multiply recurrence ----------------------
   // Lane l evaluates the points l, l + 64, l + 128, ... of a tile, so on a grid of spacing h its t
@@ -685,8 +568,13 @@ struct PeaksModel {
   static constexpr int kSeedSteps = 16;
   struct Rec {
     double g[NPK], r[NPK];
+    double b;  // the background's running value (Prep::bgrec)
   };
   static __device__ __forceinline__ unsigned rec_mask(const Prep& p) { return p.rmask; }
+  static __device__ __forceinline__ bool rec_bg(const Prep& p) { return p.bgrec; }
+  static __device__ __forceinline__ void rec_seed_bg(const Prep& p, double x0, Rec& rs) {
+    rs.b = bg_of(p, x0);
+  }
   // x0: the lane's x at the first of the next kSeedSteps points; mask: the peaks to seed (those
   // that are evaluated in this tile AND go by the recurrence)
   static __device__ __forceinline__ void rec_seed(const Prep& p, double x0, unsigned mask, Rec& rs) {
@@ -725,12 +613,19 @@ struct PeaksModel {
   // (tile-level skipping), peaks in `rmask` advance by the recurrence, the others are evaluated
   // directly (all of those as one batch when the masks are compile-time constants).  The peaks
   // are added in increasing k whatever their form.
-  template <int P>
+  template <int P, bool BGREC = false>
   static __device__ __forceinline__ void eval_mixed(const Prep& p, const double (&x)[P],
                                                     unsigned mask, unsigned rmask, Rec& rs,
                                                     double (&f)[P]) {
 #pragma unroll
-    for (int i = 0; i < P; ++i) f[i] = bg_of(p, x[i]);
+    for (int i = 0; i < P; ++i) {
+      if (BGREC) {
+        f[i] = rs.b;
+        if (NBG > 1) rs.b = rs.b + p.bgH;
+      } else {
+        f[i] = bg_of(p, x[i]);
+      }
+    }
     if constexpr (NPK * P <= 4) {
       double t[NPK * P], v[NPK * P];
       bool on[NPK * P];
@@ -875,6 +770,11 @@ struct PeaksModel {
       rmask |= ok ? (1u << k) : 0u;
     }
     p.rmask = (unsigned)__builtin_amdgcn_readfirstlane((int)rmask);
+    p.bgrec = NBG >= 1 && NBG <= 2 && p.rmask == (1u << NPK) - 1u;
+#ifdef MHX_NO_BGREC  // (build knob for A/B measurements; the oracle's mirror knows only the default)
+    p.bgrec = false;
+#endif
+    p.bgH = NBG == 2 ? uniform_f64(p.bg[1] * fn.grid_H) : 0.0;
     return p;
   }
   static __device__ __forceinline__ bool fast_ok(const Prep& p) { return p.fast; }

@@ -387,9 +387,9 @@ static int build_once(const std::vector<UserExpr>& models, const std::vector<Use
     }
   }
   const char* hdr_src[] = {kSrc_mhx_kernels_hpp, kSrc_mhx_device_hpp, kSrc_mhx_types_hpp,
-                           kSrc_mhx_h, kSrc_mhx_exp2_table_inc};
+                           kSrc_mhx_h, kSrc_mhx_exp2_table_inc, kSrc_mhx_log_table_inc};
   const char* hdr_name[] = {"mhx_kernels.hpp", "mhx_device.hpp", "mhx_types.hpp",
-                            "../../include/mhx.h", "mhx_exp2_table.inc"};
+                            "../../include/mhx.h", "mhx_exp2_table.inc", "mhx_log_table.inc"};
   // the same family defines the ahead-of-time build of this workgroup shape gets (Makefile)
   const std::string wpg = "-DMHX_WPG=" + std::to_string(fam.waves_per_group);
   const std::string famns = "-DMHX_FAMILY=w" + std::to_string(fam.waves_per_group);
@@ -417,7 +417,7 @@ static int build_once(const std::vector<UserExpr>& models, const std::vector<Use
   }
   if (!from_cache) {
     hiprtcProgram p = nullptr;
-    int rc = r.CreateProgram(&p, prog->source.c_str(), "mhx_user.hip", 5, hdr_src, hdr_name);
+    int rc = r.CreateProgram(&p, prog->source.c_str(), "mhx_user.hip", 6, hdr_src, hdr_name);
     if (rc != 0) {
       *err = std::string("hiprtcCreateProgram: ") + (r.GetErrorString ? r.GetErrorString(rc) : "?");
       return -1;

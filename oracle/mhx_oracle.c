@@ -521,6 +521,40 @@ static double mir_mexp2(double s) {
   return ldexp(p, (int)kf);
 }
 
+/* csrc/mhx_device.hpp: tlog, the table-driven log of the Poisson term (Tang's method, the SAME
+ * generated table).  Arguments within 1/16 of 1, and everything that is not a positive normal
+ * number, go through mlog() on the device, whose quotient starts from the hardware's v_rcp_f64
+ * - not an IEEE operation, so not restated: *plain is cleared and the mirror declines. */
+static const double mir_log_tab[128][2] = {
+#include "../lisp-mcmc_amd/csrc/mhx_log_table.inc"
+};
+static double mir_tlog(double x, int* plain) {
+  const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
+  const double A1 = 0x1.5555555555555p-2, A3 = 0x1.999999999999ap-3, A4 = -0x1.5555555555555p-3;
+  const uint64_t b = to_bits(x);
+  const uint32_t hx = (uint32_t)(b >> 32), lx = (uint32_t)b;
+  const uint32_t th = hx - 0x3FE60000u;
+  const int i = (int)((th >> 13) & 127u);
+  const int k = (int32_t)th >> 20;
+  const uint32_t zh = hx - (th & 0xFFF00000u);
+  const double z = from_bits(((uint64_t)zh << 32) | lx);
+  const double invc = mir_log_tab[i][0], logc = mir_log_tab[i][1];
+  const double r = fma(z, invc, -1.0);
+  const double kd = (double)k;
+  const double w = fma(kd, Ln2hi, logc);
+  const double hi = w + r;
+  const double lo = fma(kd, Ln2lo, (w - hi) + r);
+  const double r2 = r * r;
+  const double p1 = fma(r, A4, A3), p2 = fma(r, -0.25, A1);
+  const double p3 = fma(r2, p1, p2);
+  const double t = fma(r2, -0.5, lo);
+  const double res = fma(r * r2, p3, t) + hi;
+  const int ordinary = (uint32_t)(hx - 0x00100000u) < (uint32_t)(0x7ff00000u - 0x00100000u);
+  const int near_one = (uint32_t)(hx - 0x3FEE0000u) < (uint32_t)(0x3FF10000u - 0x3FEE0000u);
+  if (!ordinary || near_one) *plain = 0;
+  return res;
+}
+
 /* csrc/mhx_engine.cpp, mhx_set_dataset: x is a uniform grid x_0 + i h to 8 ulp of max |x| ->
  * 64 h (the step between two successive points of one lane), else 0 */
 static int mir_no_recurrence = 0; /* orc_mirror_set_recurrence(0): MHX_NO_RECURRENCE=1's twin */
@@ -596,13 +630,15 @@ static double mir_bound_penalty(double p, double lo, double hi) {
 #define MIR_TILE 1024
 
 /* returns NaN with *supported = 0 when the problem is outside the mirrored kernel */
-static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported) {
+static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported,
+                            int logfact_double) {
   double local[MHX_MAX_FN_PARAMS];
   gather(f, theta, local);
-  if (f->model != MHX_MODEL_GAUSS_PEAKS || f->lik != MHX_LIK_NORMAL) {
+  if (f->model != MHX_MODEL_GAUSS_PEAKS || (f->lik != MHX_LIK_NORMAL && f->lik != MHX_LIK_POISSON)) {
     *supported = 0;
     return NAN;
   }
+  const int poisson = f->lik == MHX_LIK_POISSON;
   const int nbg = f->shape[0], npk = f->shape[1];
   const double ksl2e = 1.2011224087864497594; /* sqrt(log2 e) */
   double iw[MHX_MAX_FN_PARAMS], cc[MHX_MAX_FN_PARAMS], A[MHX_MAX_FN_PARAMS];
@@ -636,18 +672,35 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
     rq[k] = mir_mexp2(2.0 * rnd2[k]);
     rec[k] = fast && gH != 0.0 && (fabs(dl) * 16.0 <= 1.0);
   }
+  /* ... and when EVERY peak goes by the recurrence, a constant or linear background does too
+   * (Prep::bgrec): b(x + 64 h) = b(x) + 64 h b1, re-seeded with the peaks */
+  int bgrec = nbg >= 1 && nbg <= 2;
+  for (int k = 0; k < npk; ++k) bgrec = bgrec && rec[k];
+  const double bgH = nbg == 2 ? local[1] * gH : 0.0;
   double acc0[MIR_LANES] = {0}, acc1[MIR_LANES] = {0};
   long double csum = 0.0L;
   const double half_log_2pi = -0.5 * log(2.0 * M_PI);
-  for (size_t i = 0; i < f->n; ++i)
-    csum += (long double)(half_log_2pi + (-1.0 * log(f->sigma[i])));
+  if (!poisson) {
+    for (size_t i = 0; i < f->n; ++i)
+      csum += (long double)(half_log_2pi + (-1.0 * log(f->sigma[i])));
+  } else {
+    /* mhx_set_dataset: -sum_i log k_i!, each factorial the single-float running sum of M:379-380
+     * (or lgamma in binary64), added up in a long double */
+    for (size_t i = 0; i < f->n; ++i)
+      csum -= (long double)orc_log_factorial(f->y[i], logfact_double);
+  }
+  int plain_log = 1;
   /* lane l of the chain's wave takes the points l, l + 64, ... ; 16 successive points of a lane
    * (1024 of the wave: MIR_TILE) are one seeding period of the recurrence */
   for (size_t base = 0; base < f->n; base += MIR_TILE) {
     for (size_t lane = 0; lane < MIR_LANES; ++lane) {
       if (base + lane >= f->n) break;
-      double g[MHX_MAX_FN_PARAMS], r[MHX_MAX_FN_PARAMS];
+      double g[MHX_MAX_FN_PARAMS], r[MHX_MAX_FN_PARAMS], bgv = 0.0;
       const double x0 = f->x[base + lane];
+      if (bgrec) {
+        bgv = local[nbg - 1];
+        for (int j = nbg - 2; j >= 0; --j) bgv = fma(bgv, x0, local[j]);
+      }
       for (int k = 0; k < npk; ++k)
         if (rec[k]) {
           const double ts = fma(x0, iw[k], cc[k]);
@@ -660,7 +713,12 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
         const double s = f->sigma[i];
         const double w = 1.0 / s, yw = f->y[i] * w, x = f->x[i];
         double m = nbg > 0 ? local[nbg - 1] : 0.0;
-        for (int j = nbg - 2; j >= 0; --j) m = fma(m, x, local[j]);
+        if (bgrec) {
+          m = bgv;
+          if (nbg > 1) bgv = bgv + bgH;
+        } else {
+          for (int j = nbg - 2; j >= 0; --j) m = fma(m, x, local[j]);
+        }
         for (int k = 0; k < npk; ++k) {
           if (rec[k]) {
             m = fma(A[k], g[k], m);
@@ -670,6 +728,14 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
             const double t = fma(x, iw[k], cc[k]);
             m = fma(A[k], fast ? mir_exp2_negsq(t) : mir_exp2_negsq_safe(t), m);
           }
+        }
+        if (poisson) { /* (- (* k (log lambda)) lambda ...) M:383; acc = acc + term */
+          const double tt = fma(f->y[i], mir_tlog(m, &plain_log), -m);
+          if (kk & 1)
+            acc1[lane] = acc1[lane] + tt;
+          else
+            acc0[lane] = acc0[lane] + tt;
+          continue;
         }
         const double rr = fma(-m, w, yw);
         if (kk & 1)
@@ -684,6 +750,13 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
   for (int m = 32; m >= 1; m >>= 1) {
     for (int l = 0; l < MIR_LANES; ++l) nv[l] = v[l] + v[l ^ m];
     memcpy(v, nv, sizeof v);
+  }
+  if (poisson) {
+    if (!plain_log) { /* some rate went through the device's mlog(): not restated */
+      *supported = 0;
+      return NAN;
+    }
+    return v[0] + (double)csum;
   }
   return fma(-0.5, v[0], (double)csum);
 }
@@ -704,7 +777,7 @@ double orc_logpost_mirror(const orc_problem* p, const double* theta, double* par
   int ok = 1;
   double ll = 0.0, lp = 0.0;
   for (int k = 0; k < p->K && ok; ++k) {
-    double v = mir_loglik_fn(&p->fn[k], theta, &ok);
+    double v = mir_loglik_fn(&p->fn[k], theta, &ok, p->logfact_double);
     ll = k == 0 ? v : ll + v;
     double q = mir_logprior_fn(&p->fn[k], theta);
     lp = k == 0 ? q : lp + q;

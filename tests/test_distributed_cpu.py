@@ -114,3 +114,25 @@ def test_world2_gloo_pooled_allreduce(orc):
         for i in range(cnt):
             assert np.array_equal(thetas[i], ws[off + i].last()[0])
     assert full[0] > 100
+
+
+def test_c_abi_partition_and_group_without_a_device():
+    """mhx_group_partition (host logic, no device needed) is the sharding rule of the Python
+    plumbing; mhx_group_create fails loudly without a GPU (no CPU path)"""
+    sys.path.insert(0, ROOT)
+    import lisp_mcmc_amd as mhx
+    from lisp_mcmc_amd import distributed as mdist
+    for total in (1, 7, 8, 13, 4096, 524288):
+        for world in (1, 2, 3, 8):
+            if total < world:
+                continue
+            assert [mhx.partition(total, world, r) for r in range(world)] == \
+                   [mdist.shard(total, world, r) for r in range(world)]
+    with pytest.raises(mhx.MhxError):
+        mhx.partition(10, 0, 0)
+    n = C.c_int(-1)
+    if mhx.capi.lib().mhx_device_count(C.byref(n)) == mhx.capi.OK and n.value > 0:
+        return  # a GPU is present: tests/test_gpu_group.py covers the rest
+    with pytest.raises(mhx.MhxError) as ei:
+        mhx.Group(16, 2, devices=[0, 1])
+    assert ei.value.code == mhx.capi.EDEVICE

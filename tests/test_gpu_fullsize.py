@@ -44,6 +44,7 @@ def test_c2_logpost_sample_vs_oracle_and_slot_independence(mhx, orc, c2):
     for c in (0, 1, 2, 3, 17, 511, 999):
         ref = op.logpost(th[c])
         assert abs(got[c] - ref) <= REL * op.abs_terms(th[c]), c
+        assert got[c] == op.logpost_mirror(th[c]), c  # the restated kernel: every bit
     for c in range(1000, 4096):
         assert got[c] == got[(c - 1000) % 8]
     e.close()
@@ -227,6 +228,7 @@ def test_c3_logpost_sample_vs_oracle_and_slot_independence(mhx, orc, c3):
         tol = REL * op.abs_terms(th8[c])
         assert abs(got8[c] - ref) <= tol, (c, got8[c], ref)
         assert abs(parts8[c][0] - pr[0]) <= tol and parts8[c][1] == pr[1] == 0.0
+        assert got8[c] == op.logpost_mirror(th8[c]), c  # ... and the restated kernel: every bit
     # a vector outside its bounds box: the prior part carries the penalty (M:360)
     out = th8[0].copy()
     out[2] = c3.theta_star[2] * 1.7

@@ -108,3 +108,45 @@ def test_guarded_exp_path_is_the_chains_own_choice(mhx, orc, n):
     keep = [i for i in range(32) if i not in narrow]
     assert np.array_equal(got[keep], got2[keep])
     e.close()
+
+
+@pytest.mark.parametrize("n", [1, 64, 1025, 3000, 40000])
+@pytest.mark.parametrize("logfact_double", [False, True])
+def test_poisson_logpost_equals_mirror(mhx, orc, n, logfact_double):
+    """BASELINE config 3's kernel (five Gaussian peaks, log-poisson, M:379-383 through
+    M:402-416) against its restatement: table-driven log, masked pads, 4-point blocks, the
+    recurrence where the grid allows it - every bit"""
+    s = pb.poisson_peaks(n=n, seed=200 + n)
+    op = s.oracle(orc, logfact_double=logfact_double)
+    e = s.engine(mhx, 1, poisson_logfact_double=logfact_double)
+    th = pb.perturbed(s.theta_star, 12, 0.02, seed=n)
+    th[2, 3] *= 0.05
+    th[3, 6] *= 4.0
+    th[4] = s.theta_star * 1.6   # outside the bounds box
+    got, parts = e.logpost(th, parts=True)
+    for i, t in enumerate(th):
+        ref, rp = op.logpost_mirror(t, parts=True)
+        assert np.isfinite(ref)
+        assert got[i] == ref and parts[i, 0] == rp[0] and parts[i, 1] == rp[1], (n, i)
+    e.close()
+
+
+def test_poisson_walk_equals_mirror(mhx, orc):
+    s = pb.poisson_peaks(n=6000, seed=77)
+    op = s.oracle(orc)
+    C_, n = 4, 1500
+    e = s.engine(mhx, C_, seed=23)
+    th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=3)
+    l0 = np.diag(0.002 * np.abs(s.theta_star))
+    e.init_chains(th0)
+    e.adaptive_begin(n, 10.0, 1, l_matrix=l0)
+    e.adaptive_advance(1 << 40)
+    st = e.state()
+    for c in range(C_):
+        w = orc.Walker(op, th0[c], mirror=True)
+        w.adaptive_begin(n, 10.0, 1, l_matrix=l0, seed=23, chain_id=c)
+        w.adaptive_advance(1 << 40)
+        th, pr = w.last()
+        assert st["age"][c] == w.age
+        assert np.array_equal(st["theta"][c], th) and st["logpost"][c] == pr, c
+    e.close()

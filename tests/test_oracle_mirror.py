@@ -36,8 +36,34 @@ def test_mirror_declines_what_the_kernel_does_differently(orc):
     th[4] = 1e-4                     # |t| ~ 3000-8000: beyond the table form's range (2^23 > t^2)
     a, m = op.logpost(th), op.logpost_mirror(th)
     assert np.isfinite(a) and abs(a - m) <= REL * op.abs_terms(th)
-    p = pb.poisson_peaks(n=50).oracle(orc)
-    assert np.isnan(p.logpost_mirror(pb.poisson_peaks(n=50).theta_star))
+    # other models / likelihoods are not restated: the mirror says so with a NaN
+    g = pb.global_fit(n_each=40, n_sets=2)
+    assert np.isnan(g.oracle(orc).logpost_mirror(g.theta_star))
+    # a Poisson rate within 1/16 of 1 goes through the device's mlog() (hardware reciprocal)
+    sp = pb.poisson_peaks(n=50)
+    t1 = sp.theta_star.copy()
+    t1[0] = 1.01
+    t1[1::3] = 0.0
+    assert np.isnan(sp.oracle(orc).logpost_mirror(t1))
+
+
+@pytest.mark.parametrize("n,logfact_double", [(1, False), (64, False), (1000, True), (1025, False),
+                                              (40000, False), (100000, True)])
+def test_poisson_mirror_within_tolerance_of_faithful(orc, n, logfact_double):
+    """BASELINE config 3's kernel restated: five Gaussian peaks (recurrence where the grid is
+    fine enough, direct table exp elsewhere), the table-driven log of the Poisson term, the
+    single-float log-factorials of M:379-380"""
+    s = pb.poisson_peaks(n=n, seed=n + 3)
+    op = s.oracle(orc, logfact_double=logfact_double)
+    th = pb.perturbed(s.theta_star, 6, 0.02, seed=n)
+    th[2, 3] *= 0.05                # a narrow peak: direct form
+    th[3, 6] *= 4.0                 # a wide one
+    for t in th:
+        a, pa = op.logpost(t, parts=True)
+        b, pm = op.logpost_mirror(t, parts=True)
+        assert np.isfinite(a) and np.isfinite(b)
+        assert abs(pa[0] - pm[0]) <= REL * op.abs_terms(t), (n, pa[0], pm[0])
+        assert pa[1] == pm[1] or abs(pa[1] - pm[1]) <= 4 * PRIOR_ULP * s.d
 
 
 def test_mirror_walker_tracks_faithful_walker(orc):
