@@ -135,12 +135,18 @@ def _share_hip_runtime_with_torch():
         spec = None
     if spec is None or not spec.submodule_search_locations:
         return
-    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    cand = os.path.join(libdir, "libamdhip64.so")
     if os.path.exists(cand):
         try:
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
         except OSError:
-            pass
+            return
+        # ... and the RCCL that was built against THAT runtime, should libmhx need one
+        # (mhx_comm_init_rank / mhx_group_create load it lazily)
+        rccl = os.path.join(libdir, "librccl.so")
+        if os.path.exists(rccl):
+            os.environ.setdefault("MHX_RCCL_LIBRARY", rccl)
 
 
 def lib():

@@ -102,9 +102,13 @@ Rccl& rccl() {
   if (tried) return r;
   tried = true;
   // the soname first: a host that already has RCCL loaded (PyTorch does) shares that instance
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+  // MHX_RCCL_LIBRARY: the copy that belongs to the HIP runtime this process uses (the Python
+  // binding points it at PyTorch's bundled librccl.so when it shares PyTorch's libamdhip64)
+  const char* names[] = {getenv("MHX_RCCL_LIBRARY"), "librccl.so.1", "librccl.so",
+                         "/opt/rocm/lib/librccl.so"};
   for (const char* n : names) {
-    r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!n || !*n) continue;
+    r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NODELETE);
     if (r.h) break;
   }
   if (!r.h) return r;

@@ -48,7 +48,7 @@ def test_walker_save_load_roundtrip(mhx, tmp_path, golden):
     path = str(tmp_path / "walker001.wlk")
     mhx.walker_save(w, path, 200)
     text = open(path).read()
-    assert text.startswith("(:FN (") and "#S(WALKER-STEP :PROB" in text and ":PARAM-KEYS (:B :M)" in text
+    assert text.startswith("(:FN (") and "(:PROB " in text and ":PARAM-KEYS (:B :M)" in text
     w2 = mhx.walker_load(path, function=mhx.models.line("b", "m"), quiet=True, seed=5)
     a = mhx.walker_get(w, get=":steps", take=200)
     b = mhx.walker_get(w2, get=":steps", take=1000)

@@ -20,9 +20,9 @@ def mhx():
     return lisp_mcmc_amd
 
 
-def _walk(obj, th0, iters):
+def _walk(obj, th0, iters, l_matrix=None):
     obj.init_chains(th0)
-    obj.adaptive_begin(30000, 10.0, 1)
+    obj.adaptive_begin(30000, 10.0, 1, l_matrix=l_matrix)
     left = iters
     while left > 0:
         obj.adaptive_advance(min(left, 150))
@@ -89,7 +89,8 @@ def test_pooled_tick_over_two_engines(mhx):
     e = s.engine(mhx, C_, seed=11, adapt_mode=mode)
     g = mhx.Group(C_, s.d, s.K, devices=[0, 0], seed=11, adapt_mode=mode)
     s.apply(g)
-    a, b = _walk(e, th0, 200), _walk(g, th0, 200)
+    l0 = np.diag(0.01 * np.abs(s.theta_star))  # (from diag(theta), M:899, nothing would move yet)
+    a, b = _walk(e, th0, 200, l0), _walk(g, th0, 200, l0)
     assert np.array_equal(a["theta"], b["theta"])  # nothing pooled has been adopted yet
     pe, p0, p1 = e.pooled(), g.engines[0].pooled(), g.engines[1].pooled()
     assert pe["refreshes"] == p0["refreshes"] == p1["refreshes"] == 1
