@@ -770,7 +770,9 @@ struct PeaksModel {
       rmask |= ok ? (1u << k) : 0u;
     }
     p.rmask = (unsigned)__builtin_amdgcn_readfirstlane((int)rmask);
-    p.bgrec = NBG >= 1 && NBG <= 2 && p.rmask == (1u << NPK) - 1u;
+    // (<= 2 peaks: with more, the second copy of the run-time-masked tile loop costs more than
+    // the reads it saves - config 3: 6.1e5 -> 4.5e5 chain-steps/s, measured)
+    p.bgrec = NBG >= 1 && NBG <= 2 && NPK <= 2 && p.rmask == (1u << NPK) - 1u;
 #ifdef MHX_NO_BGREC  // (build knob for A/B measurements; the oracle's mirror knows only the default)
     p.bgrec = false;
 #endif

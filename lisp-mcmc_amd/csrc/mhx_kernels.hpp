@@ -340,9 +340,8 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
               }
             }
           } else {
-            // more peaks: wave-uniform branches around each peak
-            if (bgrec) tile_body(tm, rmask & tm, BoolC<true>{});
-            else tile_body(tm, rmask & tm, nobg);
+            // more peaks: wave-uniform branches around each peak (never bgrec: PeaksModel::prepare)
+            tile_body(tm, rmask & tm, nobg);
           }
         } else {
           tile_body(CMask<~0u>{}, CMask<0u>{}, nobg);

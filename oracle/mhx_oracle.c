@@ -674,7 +674,7 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
   }
   /* ... and when EVERY peak goes by the recurrence, a constant or linear background does too
    * (Prep::bgrec): b(x + 64 h) = b(x) + 64 h b1, re-seeded with the peaks */
-  int bgrec = nbg >= 1 && nbg <= 2;
+  int bgrec = nbg >= 1 && nbg <= 2 && npk <= 2; /* (PeaksModel::prepare: at most two peaks) */
   for (int k = 0; k < npk; ++k) bgrec = bgrec && rec[k];
   const double bgH = nbg == 2 ? local[1] * gH : 0.0;
   double acc0[MIR_LANES] = {0}, acc1[MIR_LANES] = {0};
