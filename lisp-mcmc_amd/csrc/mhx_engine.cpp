@@ -108,7 +108,7 @@ Rccl& rccl() {
                          "/opt/rocm/lib/librccl.so"};
   for (const char* n : names) {
     if (!n || !*n) continue;
-    r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NODELETE);
+    r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     if (r.h) break;
   }
   if (!r.h) return r;
