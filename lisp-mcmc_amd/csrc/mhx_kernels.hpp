@@ -21,6 +21,7 @@
 namespace mhx {
 inline namespace MHX_FAMILY {
 
+constexpr int kCurParams = 32;
 struct GroupLds {
   // the tables of tlog() and mexp2_negsq(): 6 KiB.  FIRST member: the split-mode sweep kernel,
   // which stages no tiles, allocates only this much dynamic LDS (kSweepLdsBytes), and the device
@@ -30,6 +31,9 @@ struct GroupLds {
   double prop[kWavesPerGroup][MHX_MAX_PARAMS];     // proposal theta' of each wave, 4 KiB
   double prm[kWavesPerGroup][MHX_MAX_FN_PARAMS + 4];
   double park[kWavesPerGroup][12];  // a ChainPark per wave: the chain's scalars during a sweep
+  // the chain's position theta while a stepping kernel runs, for d <= kCurParams (beyond that it
+  // is re-read from HBM): two L2 round trips less per iteration of a latency-bound single walker
+  double cur[kWavesPerGroup][kCurParams];
   int resident;  // 1: tile 0 of the problem's only function sits in tiles[0] (FnDesc::solo)
 };
 constexpr unsigned kSweepLdsBytes = sizeof(LdsHead);  // dynamic LDS of k_split_sweep
@@ -174,7 +178,11 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
         // that is beyond what the unroller accepts, and a rolled loop would lose the pipeline):
         // one section per tile in the 8-wave family, one or two in the 16-wave family
         constexpr int NIT = kTilePoints / kWave / P;
-        constexpr int NIN = NIT > 8 ? 8 : NIT;
+#ifndef MHX_NIN_MASKED
+#define MHX_NIN_MASKED 8  // unrolled iterations per section of the 4-point (run-time mask) loops
+#endif
+        constexpr int kMaxIn = (P == MHX_PPI) ? 8 : MHX_NIN_MASKED;
+        constexpr int NIN = NIT > kMaxIn ? kMaxIn : NIT;
         constexpr int NSEC = NIT / NIN;
         static_assert(kTilePoints % (kWave * P) == 0 && NIT % NIN == 0, "whole sections per tile");
         // points of this tile that are data (the rest are neutral pads): short datasets such as
@@ -1091,6 +1099,8 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
   ChainRegs r;
   r.status = MHX_CHAIN_DONE;
   if (valid) chain_load(S, c, d, r);
+  const bool cur_in_lds = d <= kCurParams;
+  if (valid && cur_in_lds && lane_id() < d) lds.cur[w][lane_id()] = S.theta[c * d + lane_id()];
   double* Lc = S.L + (valid ? c : 0) * d * d;
   const uint64_t gchain = (uint64_t)(S.chain_offset + c);
   Ring ring;
@@ -1179,7 +1189,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
       const double rv = rng_lane_value(S.seed, gchain, r.draw, d);
       r.draw++;
       u = readlane_f64(rv, 63);
-      thp = propose(Lc, d, rv, chain_theta(S, c, d));
+      thp = propose(Lc, d, rv, cur_in_lds ? (l < d ? lds.cur[w][l] : 0.0) : chain_theta(S, c, d));
       if (l < d) lds.prop[w][l] = thp;
     }
     if constexpr (SPLIT) {  // hand the proposal to the sweep launch and stop here
@@ -1219,7 +1229,10 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
       const bool take =
           __builtin_amdgcn_readfirstlane((int)mh_accept(prob1, r.prob0, r.T, u)) != 0;
       if (take) r.prob0 = prob1;
-      add_step(S, c, d, r, take ? (l < d ? lds.prop[w][l] : 0.0) : chain_theta(S, c, d), take);
+      const double th_now = take ? (l < d ? lds.prop[w][l] : 0.0)
+                                 : (cur_in_lds ? (l < d ? lds.cur[w][l] : 0.0) : chain_theta(S, c, d));
+      if (take && cur_in_lds && l < d) lds.cur[w][l] = th_now;
+      add_step(S, c, d, r, th_now, take);
     }
     if (plain) {
       r.loop_i++;

@@ -19,7 +19,11 @@ enum SpecId {
   SPEC_POLY8_NORMAL = 5,     // degree-7 polynomial
   SPEC_LORDER_NORMAL = 6,    // test.lisp's 6-parameter lineshape
   SPEC_GAUSS22_CUTOFF = 7,
+#ifdef MHX_AOT_G23
+  SPEC__COUNT = 9
+#else
   SPEC__COUNT = 8
+#endif
 };
 
 int select_spec(const ProblemDesc& P);

@@ -497,6 +497,11 @@ int rtc_build(const std::vector<UserExpr>& models, const std::vector<UserExpr>& 
     return build_once(models, priors, builtin_fallback, with_split, fam, pinned, prog, err);
   int rc = build_once(models, priors, builtin_fallback, with_split, fam, 4, prog, err);
   if (rc != 0) return rc;
+  // Only the 8-wave family can trade occupancy for registers: a 1024-thread workgroup puts 4
+  // waves on every SIMD whatever the bound says, and asking the compiler for "2" there only
+  // changes its scheduling for the worse (measured: bench.py --workload g23, 1.5e7 -> 4.5e6
+  // chain-steps/s).
+  if (fam.threads > 512) return 0;
   int scratch = 0;
   if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, prog->f_adaptive) !=
           hipSuccess ||
