@@ -393,8 +393,21 @@ static int build_once(const std::vector<UserExpr>& models, const std::vector<Use
   // the same family defines the ahead-of-time build of this workgroup shape gets (Makefile)
   const std::string wpg = "-DMHX_WPG=" + std::to_string(fam.waves_per_group);
   const std::string famns = "-DMHX_FAMILY=w" + std::to_string(fam.waves_per_group);
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                        wpg.c_str(), famns.c_str()};
+  // MHX_RTC_FLAGS: extra compiler options, blank separated (tuning experiments: -DMHX_PPI_MASKED=2 ...)
+  std::vector<std::string> extra;
+  if (const char* xf = getenv("MHX_RTC_FLAGS")) {
+    std::istringstream is(xf);
+    std::string w;
+    while (is >> w) extra.push_back(w);
+  }
+  // -DMHX_PPI_MASKED=2: the run-time-masked tile loops (more than two peaks) with 2 points per
+  // iteration instead of the ahead-of-time build's 4.  Half the loop body: kernels loaded with
+  // hipModuleLoadData lose far more than ahead-of-time ones once their hot loop outgrows the
+  // instruction cache (bench.py --workload g23: 4.5e6 chain-steps/s with 4 points, 1.28e7 with 2;
+  // the same kernel built ahead of time: 1.48e7 / 1.41e7).
+  std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                                   wpg.c_str(), famns.c_str(), "-DMHX_PPI_MASKED=2"};
+  for (const std::string& x : extra) opts.push_back(x.c_str());
   int vmaj = 0, vmin = 0;
   if (r.Version) (void)r.Version(&vmaj, &vmin);
   std::string key = "mhx-rtc-1|hiprtc " + std::to_string(vmaj) + "." + std::to_string(vmin) + "|";
@@ -422,7 +435,7 @@ static int build_once(const std::vector<UserExpr>& models, const std::vector<Use
       *err = std::string("hiprtcCreateProgram: ") + (r.GetErrorString ? r.GetErrorString(rc) : "?");
       return -1;
     }
-    rc = r.CompileProgram(p, 6, opts);
+    rc = r.CompileProgram(p, (int)opts.size(), opts.data());
     size_t ls = 0;
     if (r.GetProgramLogSize(p, &ls) == 0 && ls > 1) {
       prog->log.resize(ls);
