@@ -206,9 +206,15 @@ def main():
         # engine's stream between the statistics kernels and the factorisation, no host
         # synchronisation, no Python in the data path.  torch.distributed only carries the 128-byte
         # communicator id from rank 0 to the others (and the barriers / max of the contract).
-        uid = [mhx.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        e.comm_init_rank(uid[0], rank, world)
+        collective = "libmhx RCCL communicator (ncclAllReduce on the engine's stream)"
+        try:
+            uid = [mhx.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            e.comm_init_rank(uid[0], rank, world)
+        except Exception as ex:  # librccl not loadable by libmhx: the torch.distributed hook instead
+            from lisp_mcmc_amd import distributed as mdist
+            e.set_allreduce(mdist.torch_allreduce_hook(dist), device_buffer=True)
+            collective = "torch.distributed all_reduce hook (libmhx RCCL unavailable: %s)" % ex
     # per-chain start: theta* (1 + 0.01 N(0,1)), keyed by GLOBAL chain id
     rng = np.random.Generator(np.random.Philox(key=0x5EED0002 + rank))
     th0 = spec.theta_star[None, :] * (1.0 + 0.01 * rng.standard_normal((chains, spec.d)))
@@ -327,6 +333,7 @@ def main():
                    "adaptation": ("pooled covariance, all-reduce of %d doubles / 200 iterations" % (1 + spec.d + spec.d ** 2))
                    if pooled else "faithful per-walker (no collective)",
                    "parallelism": "chains sharded over %d GPU(s)" % world,
+                   **({"collective": collective} if (pooled and dist is not None) else {}),
                    "kernel": "k_adaptive @ " + e.kernel_name()},
         "roofline": roof,
     }

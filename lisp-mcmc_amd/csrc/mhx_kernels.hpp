@@ -1211,12 +1211,16 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     // it in registers, so the sweep has the whole register file and nothing goes to scratch
     static_assert(sizeof(ChainPark) <= sizeof(lds.park[0]), "ChainPark slot");
     ChainPark& slot = *reinterpret_cast<ChainPark*>(lds.park[w]);
+#ifndef MHX_NO_PARK  // (build knob for A/B measurements)
     if constexpr (!SPLIT) chain_park(slot, r, u);
+#endif
     if constexpr (SPLIT)
       prob1 = split_logpost<Spec>(P, S, c, running, lds, w, &ll, &lp);
     else
       prob1 = group_logpost<Spec>(P, running, lds, w, &ll, &lp);
+#ifndef MHX_NO_PARK
     if constexpr (!SPLIT) chain_unpark(slot, r, u);
+#endif
     // the butterfly leaves the same bits in every lane: scalar from here on, and with it the
     // accept decision and every counter of the chain changed under it
     prob1 = uniform_f64(prob1);
