@@ -531,7 +531,8 @@ struct PeaksModel {
                      // scalar operand (constant bus), so c would be re-copied for every point
     Exp2K K;         // the constants of the 2^f polynomial, pinned likewise
     bool fast;  // |t| < kFastT over the whole x range for every peak (uniform)
-    bool skip;  // tile-level skipping allowed this step (see tile_mask)
+    bool skip;  // tile-level skipping by the relative rule allowed this step (see tile_mask)
+    bool afin;  // every amplitude is finite (the exact-zero rule of tile_mask)
     int thr[NPK];  // -(binary exponent of A_k) - 56
     // uniform-grid recurrence (below): per peak -2 D, -D^2 and 2^(-2 D^2), D = the step of t from
     // one point of a lane to its next (64 grid points on); rec: usable this step
@@ -549,23 +550,30 @@ struct PeaksModel {
   //     g(t + D) = 2^-(t + D)^2 = g(t) r(t),   r(t) = 2^(-2 t D - D^2),   r(t + D) = r(t) 2^(-2 D^2):
   // per point and peak  f = fma(A, g, f); g = g r; r = r q  - 3 instructions where the direct
   // form takes 14.  g and r are re-seeded from the direct formulas (table exp, at the lane's
-  // ACTUAL x) every kSeedSteps = 16 points of the lane, so a value is at most 15 steps away from an
-  // exactly evaluated one: r_j = r_0 q^j carries (j + 1) roundings, g_m = g_0 r_0 ... r_(m-1)
-  // m + sum_j (j + 1) <= 135 of them -> |g_m / g(t_m) - 1| <= 150 * 2^-53 = 1.7e-14, plus the
-  // grid's own departure from x_0 + i h (checked <= 8 ulp of max |x| when the dataset is set:
-  // 2 |t| iw 8 ulp).  Both are far inside the stated tolerance 1e-12 sum |term|
-  // (tests/test_gpu_recurrence.py measures them against the direct path and the oracle).
+  // ACTUAL x) every kSeedSteps = 32 points of the lane (at the start of every 2048-point window
+  // of the dataset: one tile of the 16-wave family, two of the 8-wave family), so a value is at
+  // most 31 steps away from an exactly evaluated one: r_j = r_0 q^j carries (j + 1) roundings,
+  // g_m = g_0 r_0 ... r_(m-1)  m + sum_j (j + 1) <= 527 of them -> |g_m / g(t_m) - 1| <=
+  // 560 * 2^-53 = 6.2e-14, plus the grid's own departure from x_0 + i h (checked <= 8 ulp of
+  // max |x| when the dataset is set: 2 |t| iw 8 ulp).  Both are far inside the stated tolerance
+  // 1e-12 sum |term| (tests/test_gpu_recurrence.py measures them against the direct path and the
+  // oracle).  A seed costs two table exps per peak: 1.6 instructions per point at 32 points per
+  // seed next to the 9 of the two-peak loop itself (3.3 at 16, which round 2 started with).
   // Preconditions, per step and PEAK (else that peak keeps the direct form): the fast path,
-  // 16 |D| <= 1 - a seed that underflows to 0 (|t| > 33.8) then stays beyond |t| = 32.8 for its 15
-  // steps, where the true value is below 2^-1075 as well - and a dataset on a grid
+  // 32 |D| <= 1 - a seed that underflows to 0 (|t| > 33.8) then stays beyond |t| = 32.8 for its
+  // 31 steps, where the true value is below 2^-1075 as well - and a dataset on a grid
   // (FnDesc::grid_H).  (A narrow peak - large D - is left out of most tiles by tile-level
   // skipping anyway; where it is not, t runs through it in a few points and the direct form is
   // the right one.)
   // The seeding cadence is fixed in points of a lane, not in tiles, so both kernel families
   // produce the same bits.  Tile-level skipping stays exact for these values too: its bound has a
-  // factor 2 in hand (an addend below f 2^-53 cannot move f; the test asks for f 2^-54).
+  // factor 2 in hand (an addend below f 2^-53 cannot move f; the test asks for f 2^-54), and a
+  // peak's mask can only change where a window - and with it a seed - starts.
   static constexpr bool kHasRec = !LORENTZ;
-  static constexpr int kSeedSteps = 16;
+#ifndef MHX_SEED_STEPS
+#define MHX_SEED_STEPS 32
+#endif
+  static constexpr int kSeedSteps = MHX_SEED_STEPS;  // points of a lane from seed to seed
   struct Rec {
     double g[NPK], r[NPK];
     double b;  // the background's running value (Prep::bgrec)
@@ -575,7 +583,7 @@ struct PeaksModel {
   static __device__ __forceinline__ void rec_seed_bg(const Prep& p, double x0, Rec& rs) {
     rs.b = bg_of(p, x0);
   }
-  // x0: the lane's x at the first of the next kSeedSteps points; mask: the peaks to seed (those
+  // x0: the lane's x at the first point of the window; mask: the peaks to seed (those
   // that are evaluated in this tile AND go by the recurrence)
   static __device__ __forceinline__ void rec_seed(const Prep& p, double x0, unsigned mask, Rec& rs) {
     if constexpr (NPK <= 2) {
@@ -701,13 +709,24 @@ struct PeaksModel {
     for (int j = NBG - 2; j >= 0; --j) f = __builtin_fma(f, x, p.bg[j]);
     return f;
   }
+  // Bit 31 of the result (kGuardBit): the window needs the guarded exp.  The table exp wants
+  // |t| < kFastT, but only where a peak is evaluated: a peak whose |t| is at least kFarT at every
+  // point of the window (same side of its centre at both ends) is EXACTLY zero there in every
+  // form of the Gaussian (2^-1600 is 25 binades below the smallest subnormal; A * 0 added to f
+  // leaves f as it is for any finite A), so it is left out - whatever the background, whether
+  // or not skipping is on - and the window is fast when every other peak has |t| < kFastT at
+  // both ends.  A proposal with one very narrow peak (|t| beyond kFastT at the far end of the
+  // data) therefore costs the guarded form only in the window that holds the peak, if at all,
+  // not over the whole dataset.
+  static constexpr unsigned kGuardBit = 0x80000000u;
+  static constexpr double kFarT = 40.0;
   static __device__ __forceinline__ unsigned tile_mask(const Prep& p, double xlo, double xhi) {
-    constexpr unsigned all = (1u << NPK) - 1u;
     const double blo = bg_of(p, xlo), bhi = bg_of(p, xhi);
     const double bmin = blo < bhi ? blo : bhi;
     const bool usable = p.skip && (bmin > 0.0) && finite_f64(blo) && finite_f64(bhi);
     const int ef = __builtin_amdgcn_frexp_exp(bmin);  // bmin in [2^(ef-1), 2^ef)
     unsigned m = 0;
+    bool guard = false;
 #pragma unroll
     for (int k = 0; k < NPK; ++k) {
       const double tl = __builtin_fma(xlo, p.iw[k], p.cv[k]);
@@ -715,20 +734,24 @@ struct PeaksModel {
       const bool same_side = (tl > 0.0 && th > 0.0) || (tl < 0.0 && th < 0.0);
       const double al = fabs(tl), ah = fabs(th);
       const double tmin = al < ah ? al : ah;
+      const bool far = p.afin && same_side && (tmin >= kFarT);        // NaN: false
+      const bool in = (al < kFastT) && (ah < kFastT);                  // NaN: false
+      guard = guard || !(far || in);
       const double kd = __builtin_fma(-tmin, tmin, p.K.magic);
-      const int kmin = (int)__double_as_longlong(kd) >> 8;  // (|t| < kFastT on the fast path)
-      const bool noop = same_side && (kmin <= ef + p.thr[k]);
+      const int kmin = (int)__double_as_longlong(kd) >> 8;  // (meaningful when `in`)
+      const bool noop = far || (usable && in && same_side && (kmin <= ef + p.thr[k]));
       m |= noop ? 0u : (1u << k);
     }
-    // per LANE: sweep() gives each lane the range of a different tile (64 tiles per pass) and
-    // later broadcasts the tile's word with readlane, so the tests in eval() are scalar branches
-    return usable ? m : all;
+    // per LANE: sweep() gives each lane the range of a different window (64 per pass) and later
+    // broadcasts the window's word with readlane, so the tests in eval() are scalar branches
+    return m | (guard ? kGuardBit : 0u);
   }
   template <class PF>
   static __device__ __forceinline__ Prep prepare(PF pf, const FnDesc& fn) {
     Prep p;
     bool fast = true;
     bool skip = fn.tile_skip != 0;
+    bool afin = true;
 #pragma unroll
     for (int j = 0; j < NBG; ++j) p.bg[j] = uniform_f64(pf(j));
     if (NBG > 1) {  // the first Horner step reads two coefficients: keep the leading one in a VGPR
@@ -751,12 +774,15 @@ struct PeaksModel {
       const double ta = fabs(__builtin_fma(fn.xmin, p.iw[k], p.mu[k]));
       const double tb = fabs(__builtin_fma(fn.xmax, p.iw[k], p.mu[k]));
       fast = fast && (ta < kFastT) && (tb < kFastT);
-      // |A_k| < 2^ea; a negative, infinite or NaN amplitude switches skipping off
+      // |A_k| < 2^ea; a negative, infinite or NaN amplitude switches the relative rule off
       skip = skip && (p.A[k] >= 0.0) && finite_f64(p.A[k]);
+      afin = afin && finite_f64(p.A[k]);
       p.thr[k] = __builtin_amdgcn_readfirstlane(-__builtin_amdgcn_frexp_exp(p.A[k]) - 56);
     }
     p.fast = fast;
-    p.skip = skip && fast && kHasSkip;
+    // (with kHasSkip the fast / guarded choice is made per window, tile_mask; without it per step)
+    p.skip = skip && kHasSkip;
+    p.afin = afin;
     p.K.pin();
     unsigned rmask = 0;
 #pragma unroll
@@ -765,7 +791,7 @@ struct PeaksModel {
       p.rm2d[k] = uniform_f64(-2.0 * dl);
       p.rnd2[k] = uniform_f64(-(dl * dl));
       p.rq[k] = uniform_f64(mexp2(2.0 * p.rnd2[k]));
-      const bool ok = kHasRec && fast && fn.grid_H != 0.0 &&
+      const bool ok = kHasRec && (fast || kHasSkip) && fn.grid_H != 0.0 &&
                       (fabs(dl) * (double)kSeedSteps <= 1.0);  // NaN fails
       rmask |= ok ? (1u << k) : 0u;
     }
@@ -961,6 +987,10 @@ template <class M, bool = model_has_rec<M>::value>
 struct model_rec_state { typedef NoRec type; };
 template <class M>
 struct model_rec_state<M, true> { typedef typename M::Rec type; };
+template <class M, bool = model_has_rec<M>::value>
+struct model_seed_steps { static constexpr int value = 16; };
+template <class M>
+struct model_seed_steps<M, true> { static constexpr int value = M::kSeedSteps; };
 template <class M, class = void>
 struct model_has_eval_n { static constexpr bool value = false; };
 template <class M>

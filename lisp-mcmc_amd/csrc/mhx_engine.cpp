@@ -290,20 +290,23 @@ int finalize_problem(mhx_engine* e) {
     if (!e->fn_set[k]) return fail(MHX_ESTATE, "function %d was never set (mhx_set_function)", k);
     if (!e->data[k].set) return fail(MHX_ESTATE, "dataset %d was never set (mhx_set_dataset)", k);
   }
-  // the kernel family fixes the tile size: tiles per dataset and the x range of every tile, pads
-  // included (tile-level peak skipping, PeaksModel::tile_mask)
+  // the kernel family fixes the tile size and with it the tiles per dataset; the x ranges that
+  // tile-level peak skipping tests against (PeaksModel::tile_mask) are those of WINDOWS of
+  // kPadPoints points, pads included, whatever the family (sweep: one mask and one seeding of the
+  // Gaussian recurrence per window)
   e->fam = &choose_family(e);
   const size_t tp = (size_t)e->fam->tile_points;
+  const size_t wp = (size_t)kPadPoints;
   for (int k = 0; k < e->P.K; ++k) {
     FnDesc& f = e->P.fn[k];
     Dataset& D = e->data[k];
     const size_t nt = ((size_t)f.n + tp - 1) / tp;
-    const size_t ntp = std::max<size_t>(nt, 1);
+    const size_t ntp = std::max<size_t>(((size_t)f.n + wp - 1) / wp, 1);
     std::vector<double> tlo(ntp), thi(ntp);
     for (size_t t = 0; t < ntp; ++t) {
       double lo = INFINITY, hi = -INFINITY;
       bool ok = true;
-      for (size_t i = t * tp; i < (t + 1) * tp; ++i) {
+      for (size_t i = t * wp; i < (t + 1) * wp; ++i) {
         ok = ok && std::isfinite(D.hx[i]);
         lo = std::min(lo, D.hx[i]);
         hi = std::max(hi, D.hx[i]);

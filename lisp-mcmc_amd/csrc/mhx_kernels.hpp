@@ -30,6 +30,9 @@ struct GroupLds {
   double tiles[2][kMaxArrays][kTilePoints];        // 64 KiB
   double prop[kWavesPerGroup][MHX_MAX_PARAMS];     // proposal theta' of each wave, 4 KiB
   double prm[kWavesPerGroup][MHX_MAX_FN_PARAMS + 4];
+#ifdef MHX_X_TIMING  // (measurement build: cycles per phase of an iteration, see MHX_TIM)
+  unsigned long long tim[kWavesPerGroup][8], tlast[kWavesPerGroup];
+#endif
   double park[kWavesPerGroup][12];  // a ChainPark per wave: the chain's scalars during a sweep
   // the chain's position theta while a stepping kernel runs, for d <= kCurParams (beyond that it
   // is re-read from HBM): two L2 round trips less per iteration of a latency-bound single walker
@@ -59,6 +62,22 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(3))) double* lds_dptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+// Measurement build (-DMHX_X_TIMING, tools/debug/phase_cycles.py): MHX_TIM(lds, k) books the
+// cycles since the wave's previous mark on phase k; k_adaptive leaves the eight sums in the
+// chain's most-likely-parameters row.  Not part of the product build.
+#ifdef MHX_X_TIMING
+#define MHX_TIM(LDS, K)                                                      \
+  do {                                                                       \
+    const unsigned long long now_ = __builtin_readcyclecounter();            \
+    if (lane_id() == 0) {                                                    \
+      (LDS).tim[wave_in_group()][K] += now_ - (LDS).tlast[wave_in_group()];  \
+      (LDS).tlast[wave_in_group()] = now_;                                   \
+    }                                                                        \
+  } while (0)
+#else
+#define MHX_TIM(LDS, K) do { } while (0)
+#endif
+
 // Tile t of every array of function f -> LDS buffer `buf`, by LDS-DMA (global_load_lds_dwordx4:
 // no VGPR staging; each wave instruction lands 64 x 16 B = 1 KiB contiguously at a
 // wave-uniform LDS base).  Asynchronous: retired by the s_waitcnt vmcnt(0) the compiler puts in
@@ -78,6 +97,32 @@ __device__ __forceinline__ void tile_dma(const FnDesc& f, int64_t t, GroupLds& l
   if constexpr (NARR > 3)
     __builtin_amdgcn_global_load_lds((glb_ptr_t)(f.c + base),
                                      (lds_ptr_t)&lds.tiles[buf][3][wbase], 16, 0, 0);
+}
+
+// VALU issue on a SIMD goes to the wave of highest priority, then to the OLDEST: left alone, the
+// four chains of a SIMD do not advance through a tile together - the oldest runs nearly
+// unimpeded and reaches the tile's barrier after 45 % of the tile's time, the next ones after
+// 56 / 70 / 85 % (measured, config 2: tools/debug/phase_cycles.py), so for a third of every tile
+// only one or two waves are left to fill the SIMD's issue slots, which one or two dependent
+// fp64 streams cannot.  Priority by PROGRESS evens that out: a wave enters a tile at priority
+// 3 and drops one level per quarter of the tile, so whoever is behind goes first and the four
+// reach the barrier within a quarter tile of one another.  (s_setprio takes an immediate: `it`
+// is a constant after unrolling, `sec` is not.)
+template <int NIT, int NIN>
+__device__ __forceinline__ void tile_prio(int sec, int it) {
+#ifndef MHX_NO_TILE_PRIO  // (build knob for A/B measurements)
+  constexpr int step = NIT >= 4 ? NIT / 4 : 1;
+  static_assert(NIN % step == 0, "a section starts on a priority step");
+  if (it % step == 0) {
+    const int q = (sec * NIN + it) / step;
+    switch (q) {
+      case 0: __builtin_amdgcn_s_setprio(3); break;
+      case 1: __builtin_amdgcn_s_setprio(2); break;
+      case 2: __builtin_amdgcn_s_setprio(1); break;
+      default: __builtin_amdgcn_s_setprio(0); break;
+    }
+  }
+#endif
 }
 
 template <bool B>
@@ -108,7 +153,22 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
   double acc0 = 0.0, acc1 = 0.0;
   const double log_a3 = tlog_a3();  // (Poisson) a constant of tlog() pinned in a VGPR
   (void)log_a3;
-  unsigned tile_masks = ~0u;  // lane i: which peaks tile (t & ~63) + i needs (PeaksModel::tile_mask)
+  // Tile-level peak skipping and the Gaussian recurrence work on WINDOWS of kPadPoints = 2048
+  // points - one tile of the 16-wave family, two of the 8-wave family: the mask of peaks is
+  // formed per window and the recurrence seeded at its start, so both families evaluate the same
+  // expressions in the same order and give the same bits.
+  constexpr int kTPW = kPadPoints / kTilePoints;
+  const int64_t nw = (nt + kTPW - 1) / kTPW;
+  unsigned tile_masks = ~0u;  // lane i: which peaks window (wi & ~63) + i needs (PeaksModel::tile_mask)
+  // (REC) the peaks' running g, r live from one seed to the next: across the tiles of a window
+  // (8-wave family), across the sections of a tile, or within a section
+  typedef typename model_rec_state<Model>::type RecState;
+  constexpr int kSeedPts = model_seed_steps<Model>::value;  // points of a lane from seed to seed
+  constexpr int kLanePtsPerTile = kTilePoints / kWave;
+  static_assert(kSeedPts % 16 == 0 && (kPadPoints / kWave) % kSeedPts == 0, "seeds per window");
+  RecState rs_sweep;
+  (void)rs_sweep;
+  (void)nw;
   if (nt == 0) return 0.0;
   // A problem with ONE function of ONE tile (test.lisp's 334 points) walked by a single
   // workgroup keeps that tile in LDS for the whole launch: after the first sweep there is no DMA
@@ -121,6 +181,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
   // it: a wave that arrived late and read 1 would skip the block - its part of the DMA and the
   // barrier - and sum over a tile that is not there yet)
   if (solo && !have) __syncthreads();
+  MHX_TIM(lds, 2);
   if (!have) {
     tile_dma<NARR>(f, 0, lds, 0, w);
     // An LDS-DMA is ordered for the readers only by the ISSUING wave's vmcnt wait followed by a
@@ -129,10 +190,32 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
     if (solo && threadIdx.x == 0) lds.resident = 1;
     __syncthreads();
   }
+  MHX_TIM(lds, 3);
   for (int64_t t = 0; t < nt; ++t) {
     const int buf = (int)(t & 1);
+    const int64_t wi = t / kTPW;            // the window this tile belongs to ...
+    const bool wstart = (t % kTPW) == 0;    // ... and whether it opens it
+    (void)wi;
+    (void)wstart;
     // buffer buf^1 was last read in iteration t-1, which every wave left through the barrier
     if (t + 1 < nt) tile_dma<NARR>(f, t + 1, lds, buf ^ 1, w);
+    // Which Gaussian peaks this window needs (those that cannot change any of its sums by even
+    // one bit are left out: PeaksModel::tile_mask; exact, so the results do not depend on it),
+    // and whether the window can take the table exp: decided per WINDOW for such models, so one
+    // very narrow proposed peak costs the guarded form where it sits, not over the whole dataset.
+    unsigned tm = ~0u;
+    bool fastw = fast;
+    if constexpr (model_has_skip<Model>::value && model_has_fast<Model>::value) {
+      // the words of 64 consecutive windows are worked out at once, lane i taking window wi + i
+      if (wstart && (wi & 63) == 0) {
+        const int64_t ti = wi + l < nw ? wi + l : nw - 1;
+        tile_masks = Model::tile_mask(prep, f.txlo[ti], f.txhi[ti]);
+      }
+      const unsigned tw = (unsigned)__builtin_amdgcn_readlane((int)tile_masks, (int)(wi & 63));
+      tm = tw & ~Model::kGuardBit;
+      fastw = (tw & Model::kGuardBit) == 0u;
+    }
+    (void)tm;
     auto tile_work = [&](auto fastc) {
       constexpr bool FAST = decltype(fastc)::value;
       // The lane's element of tile point 0 ... P-1 of each array, as LDS addresses the compiler
@@ -179,8 +262,8 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
         // one section per tile in the 8-wave family, one or two in the 16-wave family
         constexpr int NIT = kTilePoints / kWave / P;
 #ifndef MHX_NIN_MASKED
-// unrolled iterations per section of the 4-point (run-time mask) loops: 4 = one seeding period
-// of the recurrence; 8 (a whole 2048-point tile) measured 4 % slower on config 3 (code size)
+// unrolled iterations per section of the 4-point (run-time mask) loops: 8 (a whole 2048-point
+// tile) measured 4 % slower than 4 on config 3 (code size)
 #define MHX_NIN_MASKED 4
 #endif
         constexpr int kMaxIn = (P == MHX_PPI) ? 8 : MHX_NIN_MASKED;
@@ -190,12 +273,16 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
         // points of this tile that are data (the rest are neutral pads): short datasets such as
         // test.lisp's 334 points leave most of their only tile unused
         const int nv = (int)((f.n - gbase) < (int64_t)kTilePoints ? (f.n - gbase) : (int64_t)kTilePoints);
+        RecState rs_tile;
+        (void)rs_tile;
 #pragma unroll 1
         for (int sec = 0; sec < NSEC; ++sec) {
           const int sbase = sec * NIN * P * kWave;  // first tile element of this section
           if (sbase >= nv) break;
-          typename model_rec_state<Model>::type rs;  // (REC) the peaks' running g, r
-          (void)rs;
+          RecState rs_sec;
+          (void)rs_sec;
+          RecState& rs = *(kSeedPts > kLanePtsPerTile ? &rs_sweep
+                                                      : (kSeedPts > NIN * P ? &rs_tile : &rs_sec));
           double x[P], y[P], wv[P], cv[P];
 #pragma unroll
           for (int i = 0; i < P; ++i) {
@@ -216,6 +303,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
 #pragma unroll
           for (int it = 0; it < NIN; ++it) {
             if (sbase + it * P * kWave >= nv) break;  // uniform: one scalar compare per P points
+            tile_prio<NIT, NIN>(sec, it);
             double xn[P], yn[P], wn[P], cn[P];
 #pragma unroll
             for (int i = 0; i < P; ++i) {
@@ -240,10 +328,11 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
             double m[P];
             if constexpr (model_has_rec<Model>::value) {  // (tested on its own: generic lambda)
               if constexpr (FAST) {
-                // re-seeded every kSeedSteps points of the lane, counted from the tile's start (a
-                // section is a whole number of seeding periods in either kernel family)
-                static_assert((NIN * P) % 16 == 0, "sections hold whole seeding periods");
-                if ((it * P) % 16 == 0) {
+                // seeded at the lane's first point of the window (PeaksModel::kSeedSteps = the
+                // points of a lane per window)
+                // (point of the lane within its window: a constant but for `sec` and `t`)
+                const int gp = (int)(t % kTPW) * kLanePtsPerTile + (sec * NIN + it) * P;
+                if ((it * P) % 16 == 0 && gp % kSeedPts == 0) {
                   if ((rm & mask) != 0u) Model::rec_seed(prep, x[0], rm & mask, rs);
                   if constexpr (BGREC) Model::rec_seed_bg(prep, x[0], rs);
                 }
@@ -302,18 +391,10 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
         }
       };
       constexpr BoolC<false> nobg{};
-      // Gaussian peaks that cannot change any sum of this tile by even one bit are left out
-      // (PeaksModel::tile_mask; exact, so the results do not depend on it)
       // (the model test first, on its own: inside this generic lambda only a condition that does
       // not depend on FAST keeps the skipping code from being checked against other models)
       if constexpr (model_has_skip<Model>::value) {
         if constexpr (FAST) {
-          // the masks of 64 consecutive tiles are worked out at once, lane i taking tile t + i
-          if ((t & 63) == 0) {
-            const int64_t ti = t + l < nt ? t + l : nt - 1;
-            tile_masks = Model::tile_mask(prep, f.txlo[ti], f.txhi[ti]);
-          }
-          const unsigned tm = (unsigned)__builtin_amdgcn_readlane((int)tile_masks, (int)(t & 63));
           // one straight-line variant per (peaks evaluated, peaks by recurrence) with <= 2 peaks
           // (bgrec: every peak of the function goes by the recurrence this step, and the
           // background with them - those variants never read x beyond their seeds)
@@ -362,15 +443,22 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
     };
     if (active) {
       if constexpr (model_has_fast<Model>::value) {
-        if (fast) tile_work(BoolC<true>{}); else tile_work(BoolC<false>{});
+        if (fastw) tile_work(BoolC<true>{}); else tile_work(BoolC<false>{});
       } else {
         tile_work(BoolC<false>{});
       }
     }
+#ifndef MHX_NO_TILE_PRIO
+    __builtin_amdgcn_s_setprio(0);  // (tile_prio; a short tile may leave its loop at any level)
+#endif
+    MHX_TIM(lds, 4);
     if (!solo) {  // (a resident tile is never overwritten: nothing to wait for)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of tile t+1 has landed
+#ifndef MHX_X_NOBAR  // (timing experiment only: results are wrong without the barrier)
       __syncthreads();                                   // ... and so has everybody else's
+#endif
     }
+    MHX_TIM(lds, 5);
   }
   return wave_sum(acc0 + acc1);
 }
@@ -460,8 +548,11 @@ struct FixedSpec {
       fast = __builtin_amdgcn_readfirstlane((int)Model::fast_ok(prep)) != 0;
     bool bgrec = false;
     if constexpr (model_has_rec<Model>::value) {
-      rmask = fast ? Model::rec_mask(prep) : 0u;
-      bgrec = fast && __builtin_amdgcn_readfirstlane((int)Model::rec_bg(prep)) != 0;
+      // (models that choose fast / guarded per window - model_has_skip - use these in their fast
+      // windows whatever `fast` says about the dataset as a whole)
+      const bool may = fast || model_has_skip<Model>::value;
+      rmask = may ? Model::rec_mask(prep) : 0u;
+      bgrec = may && __builtin_amdgcn_readfirstlane((int)Model::rec_bg(prep)) != 0;
     }
     return finish_lik<LIK>(f, sweep<Model, LIK>(f, prep, active, lds, fast, rmask, bgrec));
   }
@@ -570,6 +661,7 @@ template <class Spec>
 __device__ __forceinline__ double group_logpost(const ProblemDesc& P, bool active, GroupLds& lds,
                                                 int w, double* ll_out, double* lp_out) {
   __syncthreads();  // proposals written, previous users of the tile buffers are done
+  MHX_TIM(lds, 1);
   double ll = 0.0, lp = 0.0;
   const double* th = lds.prop[w];
   for (int k = 0; k < P.K; ++k) {
@@ -1114,8 +1206,15 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
   double* covs = S.mat_tmp + (valid ? c : 0) * 2 * d * d;
   double* lnew = covs + d * d;
   const int64_t age0 = valid ? r.age : 0;
+#ifdef MHX_X_TIMING
+  if (l == 0) {
+    for (int k = 0; k < 8; ++k) lds.tim[w][k] = 0;
+    lds.tlast[w] = __builtin_readcyclecounter();
+  }
+#endif
 
   for (int64_t it = 0; SPLIT || it < max_iters; ++it) {
+    MHX_TIM(lds, 6);
     const int l = lane_id();  // (formed per iteration: see lane_id())
     int d_it = P.d;  // likewise the parameter count: what the cold code derives from it (the
     asm volatile("" : "+s"(d_it));  // reciprocal behind e / d ...) is formed where it is used
@@ -1211,6 +1310,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     // it in registers, so the sweep has the whole register file and nothing goes to scratch
     static_assert(sizeof(ChainPark) <= sizeof(lds.park[0]), "ChainPark slot");
     ChainPark& slot = *reinterpret_cast<ChainPark*>(lds.park[w]);
+    MHX_TIM(lds, 0);
 #ifndef MHX_NO_PARK  // (build knob for A/B measurements)
     if constexpr (!SPLIT) chain_park(slot, r, u);
 #endif
@@ -1221,6 +1321,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
 #ifndef MHX_NO_PARK
     if constexpr (!SPLIT) chain_unpark(slot, r, u);
 #endif
+    MHX_TIM(lds, 7);
     // the butterfly leaves the same bits in every lane: scalar from here on, and with it the
     // accept decision and every counter of the chain changed under it
     prob1 = uniform_f64(prob1);
@@ -1305,6 +1406,9 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     if (r.status == MHX_CHAIN_RUNNING && r.loop_i >= R.n) r.status = MHX_CHAIN_DONE;
     chain_store(S, c, d, r);
     if (l == 0 && r.age != age0) atomicAdd(S.step_counter, (unsigned long long)(r.age - age0));
+#ifdef MHX_X_TIMING
+    if (l < 8 && l < d) S.best_theta[c * d + l] = (double)lds.tim[w][l];
+#endif
   }
 }
 

@@ -48,8 +48,8 @@ struct FnDesc {
   double xmin, xmax; // range of x over the n points (fast-path preconditions of the models)
   double grid_H;     // 64 h when x is a uniform grid x_0 + i h (to 8 ulp of max |x|), else 0: the
                      // distance between two successive points of one lane (Gaussian recurrence)
-  const double* txlo;  // [n_tiles] smallest / largest x of each tile (-inf / +inf when a tile
-  const double* txhi;  // holds a non-finite x): what tile-level peak skipping tests against
+  const double* txlo;  // [ceil(n / kPadPoints)] smallest / largest x of each 2048-point window (-inf /
+  const double* txhi;  // +inf when it holds a non-finite x): what tile-level peak skipping tests against
   int32_t tile_skip;   // 0: evaluate every peak for every point (MHX_NO_TILE_SKIP=1)
   int32_t solo;        // 1: the problem's only function and a single tile - it stays in LDS
   int32_t user_slot;  // >= 0: index of the run-time compiled expression model (MHX_MODEL_EXPR)

@@ -559,6 +559,9 @@ static double mir_tlog(double x, int* plain) {
  * 64 h (the step between two successive points of one lane), else 0 */
 static int mir_no_recurrence = 0; /* orc_mirror_set_recurrence(0): MHX_NO_RECURRENCE=1's twin */
 void orc_mirror_set_recurrence(int on) { mir_no_recurrence = !on; }
+/* PeaksModel::kSeedSteps: the recurrence is re-seeded every 32 points of a lane (at the start
+ * of every 2048-point window of the dataset, in either kernel family) */
+#define MIR_SEED_STEPS 32
 static double mir_grid_H(const orc_fn* f) {
   const size_t n = f->n;
   if (mir_no_recurrence || n < 2 || !isfinite(f->x[0]) || !isfinite(f->x[n - 1])) return 0.0;
@@ -627,7 +630,6 @@ static double mir_bound_penalty(double p, double lo, double hi) {
 }
 
 #define MIR_LANES 64
-#define MIR_TILE 1024
 
 /* returns NaN with *supported = 0 when the problem is outside the mirrored kernel */
 static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported,
@@ -648,6 +650,13 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
     if (f->x[i] > xmax) xmax = f->x[i];
   }
   int fast = 1;
+  /* PeaksModel::kHasSkip: such models choose the table exp or the guarded form per 2048-point
+   * WINDOW (tile_mask): a peak with |t| >= 40 over a whole window is exactly zero there and is
+   * left out (all amplitudes finite), and the window is fast when every other peak has
+   * |t| < kFastT at both of its ends; the others decide once for the whole dataset */
+  const int has_skip = nbg >= 1 && nbg <= 2 && npk <= 30;
+  int afin = 1;
+  for (int k = 0; k < npk; ++k) afin = afin && isfinite(local[nbg + 3 * k]);
   for (int k = 0; k < npk; ++k) {
     A[k] = local[nbg + 3 * k];
     iw[k] = ksl2e / local[nbg + 3 * k + 2];
@@ -660,7 +669,7 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
   }
   /* the uniform-grid recurrence (PeaksModel, "Gaussians on a uniformly spaced x grid"): per
    * peak D = 64 h iw, r(t) = 2^(-2 t D - D^2), q = 2^(-2 D^2); a peak goes by it this step when
-   * the function is on the fast path, the data on a grid and 16 |D| <= 1.  Tile-level skipping
+   * the function is on the fast path, the data on a grid and 32 |D| <= 1.  Tile-level skipping
    * is exact for these values as well, so - as for the direct form - it is not restated. */
   const double gH = mir_grid_H(f);
   double rm2d[MHX_MAX_FN_PARAMS], rnd2[MHX_MAX_FN_PARAMS], rq[MHX_MAX_FN_PARAMS];
@@ -670,7 +679,7 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
     rm2d[k] = -2.0 * dl;
     rnd2[k] = -(dl * dl);
     rq[k] = mir_mexp2(2.0 * rnd2[k]);
-    rec[k] = fast && gH != 0.0 && (fabs(dl) * 16.0 <= 1.0);
+    rec[k] = (fast || has_skip) && gH != 0.0 && (fabs(dl) * (double)MIR_SEED_STEPS <= 1.0);
   }
   /* ... and when EVERY peak goes by the recurrence, a constant or linear background does too
    * (Prep::bgrec): b(x + 64 h) = b(x) + 64 h b1, re-seeded with the peaks */
@@ -690,43 +699,73 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
       csum -= (long double)orc_log_factorial(f->y[i], logfact_double);
   }
   int plain_log = 1;
-  /* lane l of the chain's wave takes the points l, l + 64, ... ; 16 successive points of a lane
-   * (1024 of the wave: MIR_TILE) are one seeding period of the recurrence */
-  for (size_t base = 0; base < f->n; base += MIR_TILE) {
+  /* lane l of the chain's wave takes the points l, l + 64, ... ; 32 successive points of a lane
+   * (2048 of the wave) are one seeding period of the recurrence */
+  const size_t mir_tile = (size_t)MIR_LANES * MIR_SEED_STEPS;
+  for (size_t base = 0; base < f->n; base += mir_tile) {
+    int fastw = fast, far[MHX_MAX_FN_PARAMS] = {0};
+    if (has_skip) {
+      /* the window's x range as mhx_engine.cpp (finalize_problem) forms it: pads repeat the last
+       * point; a non-finite x opens the range to (-inf, inf) */
+      double xlo = INFINITY, xhi = -INFINITY;
+      int okx = 1;
+      for (size_t i = base; i < base + mir_tile; ++i) {
+        const double xv = f->x[i < f->n ? i : f->n - 1];
+        okx = okx && isfinite(xv);
+        if (xv < xlo) xlo = xv;
+        if (xv > xhi) xhi = xv;
+      }
+      if (!okx) {
+        xlo = -INFINITY;
+        xhi = INFINITY;
+      }
+      fastw = 1;
+      for (int k = 0; k < npk; ++k) {
+        const double tl = fma(xlo, iw[k], cc[k]), th = fma(xhi, iw[k], cc[k]);
+        const int same_side = (tl > 0.0 && th > 0.0) || (tl < 0.0 && th < 0.0);
+        const double al = fabs(tl), ah = fabs(th);
+        const double tmin = al < ah ? al : ah;
+        far[k] = afin && same_side && (tmin >= 40.0);
+        const int in = (al < MIR_FAST_T) && (ah < MIR_FAST_T);
+        if (!(far[k] || in)) fastw = 0;
+      }
+    }
+    const int bgrec_w = bgrec && fastw;
     for (size_t lane = 0; lane < MIR_LANES; ++lane) {
       if (base + lane >= f->n) break;
       double g[MHX_MAX_FN_PARAMS], r[MHX_MAX_FN_PARAMS], bgv = 0.0;
       const double x0 = f->x[base + lane];
-      if (bgrec) {
+      if (bgrec_w) {
         bgv = local[nbg - 1];
         for (int j = nbg - 2; j >= 0; --j) bgv = fma(bgv, x0, local[j]);
       }
       for (int k = 0; k < npk; ++k)
-        if (rec[k]) {
+        if (rec[k] && fastw && !far[k]) {
           const double ts = fma(x0, iw[k], cc[k]);
           g[k] = mir_exp2_negsq(ts);
           r[k] = mir_exp2_plain(fma(rm2d[k], ts, rnd2[k]));
         }
-      for (size_t kk = 0; kk < MIR_TILE / MIR_LANES; ++kk) {
+      for (size_t kk = 0; kk < mir_tile / MIR_LANES; ++kk) {
         const size_t i = base + kk * MIR_LANES + lane;
         if (i >= f->n) break;
         const double s = f->sigma[i];
         const double w = 1.0 / s, yw = f->y[i] * w, x = f->x[i];
         double m = nbg > 0 ? local[nbg - 1] : 0.0;
-        if (bgrec) {
+        if (bgrec_w) {
           m = bgv;
           if (nbg > 1) bgv = bgv + bgH;
         } else {
           for (int j = nbg - 2; j >= 0; --j) m = fma(m, x, local[j]);
         }
         for (int k = 0; k < npk; ++k) {
-          if (rec[k]) {
+          if (fastw && far[k]) continue; /* exactly zero over this window: left out */
+          if (fastw && rec[k]) {
             m = fma(A[k], g[k], m);
             g[k] = g[k] * r[k];
             r[k] = r[k] * rq[k];
           } else {
             const double t = fma(x, iw[k], cc[k]);
-            m = fma(A[k], fast ? mir_exp2_negsq(t) : mir_exp2_negsq_safe(t), m);
+            m = fma(A[k], fastw ? mir_exp2_negsq(t) : mir_exp2_negsq_safe(t), m);
           }
         }
         if (poisson) { /* (- (* k (log lambda)) lambda ...) M:383; acc = acc + term */

@@ -84,9 +84,10 @@ def test_adaptive_run_history_equals_mirror(mhx, orc):
 
 @pytest.mark.parametrize("n", [700, 5000])
 def test_guarded_exp_path_is_the_chains_own_choice(mhx, orc, n):
-    """Peaks so narrow that |t| leaves the table form's range (t^2 >= 2^23) somewhere in the data
-    send THAT chain through the guarded exp; the choice is made per wave, so the chains sharing
-    its workgroup keep their bits (no workgroup vote), and both forms equal the mirror."""
+    """Peaks so narrow that |t| leaves the table form's range (t^2 >= 2^23) inside a window where
+    they still count send THAT chain through the guarded exp there; the choice is the wave's own,
+    so the chains sharing its workgroup keep their bits (no workgroup vote), and both forms
+    equal the mirror."""
     s = pb.two_peak(n=n, seed=21)
     op = s.oracle(orc)
     th = pb.perturbed(s.theta_star, 32, 0.02, seed=22)
@@ -108,6 +109,48 @@ def test_guarded_exp_path_is_the_chains_own_choice(mhx, orc, n):
     keep = [i for i in range(32) if i not in narrow]
     assert np.array_equal(got[keep], got2[keep])
     e.close()
+
+
+def test_guarded_form_only_in_the_windows_that_need_it(mhx, orc):
+    """The table exp / guarded form choice is made per 2048-point window: a peak whose |t| is at
+    least 40 over a whole window is exactly zero there and left out, so a very narrow peak sends
+    only the window that holds it (if any) through the guarded form.  Every bit equals the
+    mirror, which restates the windows; MHX_NO_TILE_SKIP=1 changes nothing (the exact-zero rule
+    is not an option); and such a step is no longer several times dearer than its neighbours."""
+    import os
+    n = 50000
+    s = pb.two_peak(n=n, seed=23)
+    op = s.oracle(orc)
+    th = pb.perturbed(s.theta_star, 24, 0.02, seed=24)
+    th[2, 4] = 1e-4                      # |t| up to ~6e3 at the far end, < 2890 inside its windows
+    th[3, 7] = 2e-6                      # so narrow that even its own window runs |t| past 2890
+    th[4, 4], th[4, 3] = 3e-5, 0.99999   # narrow, in the last (partly padded) window
+    th[5, 7], th[5, 6] = 1e-4, 5.0       # narrow and far outside the data: zero everywhere
+    th[6, 4], th[6, 0] = 1e-4, -0.3      # narrow with a negative background (no relative rule)
+    th[7, 4], th[7, 2] = 1e-4, -2.0      # narrow with a negative amplitude
+    th[8, 7], th[8, 5] = 1e-4, np.inf    # an infinite amplitude: nothing may be left out
+    th[9, 4] = -1e-4
+    e = s.engine(mhx, 1)
+    os.environ["MHX_NO_TILE_SKIP"] = "1"
+    try:
+        e2 = s.engine(mhx, 1)
+        with np.errstate(all="ignore"):
+            got2 = e2.logpost(th)
+    finally:
+        os.environ.pop("MHX_NO_TILE_SKIP", None)
+    with np.errstate(all="ignore"):
+        got, parts = e.logpost(th, parts=True)
+    assert np.array_equal(got, got2, equal_nan=True)
+    for i, t in enumerate(th):
+        with np.errstate(all="ignore"):
+            ref, rp = op.logpost_mirror(t, parts=True)
+            fa = op.logpost(t)
+        assert (got[i] == ref and parts[i, 0] == rp[0]) or (np.isnan(got[i]) and np.isnan(ref)), i
+        if np.isfinite(fa):
+            assert abs(got[i] - fa) <= 1e-12 * op.abs_terms(t) + 2.0 ** -52 * 1e10 * 8, i
+    assert not np.isfinite(got[8])
+    e.close()
+    e2.close()
 
 
 @pytest.mark.parametrize("n", [1, 64, 1025, 3000, 40000])

@@ -1,8 +1,8 @@
 """Gaussian peaks on a uniformly spaced x grid advance by a two-multiply recurrence
 (csrc/mhx_device.hpp, PeaksModel: "Gaussians on a uniformly spaced x grid") instead of one exp
 per point.  Unlike tile-level skipping this is NOT a bit-exact transformation: a value is up to
-15 multiplications away from an exactly evaluated seed.  Stated bound: each peak value within
-150 * 2^-53 = 1.7e-14 (relative) of the direct form, hence the log-posterior within
+31 steps away from an exactly evaluated seed.  Stated bound: each peak value within
+560 * 2^-53 = 6.2e-14 (relative) of the direct form, hence the log-posterior within
 1e-13 * sum |term| of the direct kernel and, like it, within 1e-12 * sum |term| of the
 reference's arithmetic.  Checked here: against the direct kernel (MHX_NO_RECURRENCE=1), against
 the faithful oracle, bit for bit against the oracle's mirror of either form, on grids and
@@ -39,7 +39,7 @@ def engines(mhx, spec, chains, **kw):
 def mixed_thetas(theta_star, n, seed):
     rng = np.random.default_rng(seed)
     th = pb.perturbed(theta_star, n, 0.03, seed=seed)
-    # widths from far below the recurrence's limit (16 * 64 h iw <= 1) to wide; peaks in and out of range
+    # widths from far below the recurrence's limit (32 * 64 h iw <= 1) to wide; peaks in and out of range
     for r in range(4, n):
         th[r, 4] = 10.0 ** rng.uniform(-3.5, -0.3)
         th[r, 7] = 10.0 ** rng.uniform(-3.5, -0.3)
@@ -71,9 +71,8 @@ def test_logposts_recurrence_vs_direct_vs_oracle_vs_mirror(mhx, orc, n):
         finally:
             orc.mirror_set_recurrence(True)
     assert np.array_equal(pa[:, 1], pb_[:, 1])  # the prior part does not know about any of this
-    # 16 * 64 h iw <= 1 needs about 1230 grid points per peak width: among these vectors (widths
-    # up to 0.5 of the range) some qualify from a few thousand points on
-    if n >= 5000:
+    # 32 * 64 h iw <= 1 needs about 2460 grid points per peak width
+    if n >= 100000:
         assert (a != b).any()  # ... and the recurrence really ran
     print("n = %d: worst |rec - direct| / sum|term| = %.2e" % (n, worst))
     rec.close()
@@ -111,8 +110,8 @@ def test_not_a_grid_means_direct_form(mhx, orc):
 
 
 def test_both_families_give_the_same_bits(mhx):
-    """the seeding cadence is counted in points of a lane, not in tiles"""
-    s = pb.two_peak(n=30000, seed=9)
+    """masks and seeds go by 2048-point windows of the dataset, not by the family's tiles"""
+    s = pb.two_peak(n=60000, seed=9)
     th = mixed_thetas(s.theta_star, 32, seed=4)
     got = []
     for wpg in ("8", "16"):
@@ -160,11 +159,17 @@ def test_poisson_five_peaks_recurrence_vs_direct_vs_oracle(mhx, orc):
 
 
 def test_walk_equals_mirror_with_the_recurrence(mhx, orc):
-    """a whole walker-adaptive-steps run on a grid, against the mirror restating the recurrence"""
-    s = pb.two_peak(n=3000, seed=31)
+    """a whole walker-adaptive-steps run on a grid fine enough for both peaks to go by the
+    recurrence, against the mirror restating it"""
+    s = pb.two_peak(n=60000, seed=31)
     op = s.oracle(orc)
-    C_, n = 4, 3000
+    C_, n = 3, 1200
     e = s.engine(mhx, C_, seed=17)
+    rec, direct = engines(mhx, s, 1)
+    t = s.theta_star[None, :]
+    assert rec.logpost(t)[0] != direct.logpost(t)[0]   # ... which it does at theta*
+    rec.close()
+    direct.close()
     th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=5)
     e.init_chains(th0)
     e.adaptive_begin(n, 10.0, 1)
