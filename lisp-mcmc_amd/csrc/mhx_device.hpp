@@ -698,8 +698,15 @@ struct PeaksModel {
   // tile, bmin = min(bg(xlo), bg(xhi)) (Horner fma, monotone for NBG <= 2; every earlier peak
   // added a non-negative amount), and bmin >= 2^(ef-1).  A double g > 0 has no neighbour closer
   // than g 2^-53, so an addend below g 2^-54 leaves fma(A, e, f) == f: the peak is a no-op for
-  // every point of the tile when  ea + kmin + 1 <= ef - 55.  Preconditions (else every peak is
-  // evaluated): fast path, 1 <= NBG <= 2, all A_k finite and >= 0, bmin > 0 and finite.
+  // every point of the tile when  ea + kmin + 1 <= ef - 55.
+  // What the rule needs is a lower bound on |f| at the moment peak k is added, and the sign of
+  // nothing: while every earlier peak of the window was itself left out, f IS the background,
+  // whose magnitude over the window is at least lb = min(|bg(xlo)|, |bg(xhi)|) when both ends
+  // have the same sign - negative backgrounds and negative amplitudes included; after a peak has
+  // been evaluated the bound survives only if the background is positive and that peak's
+  // amplitude is >= 0 (f can only have grown).  Otherwise the later peaks of that window are
+  // evaluated.  Preconditions: 1 <= NBG <= 2, every amplitude finite, bg finite and of one
+  // sign at both ends of the window, the window on the table-exp path.
   static constexpr bool kHasSkip = !LORENTZ && NBG >= 1 && NBG <= 2 && NPK <= 30;
   static constexpr int kPeaks = NPK;
   static __device__ __forceinline__ double bg_of(const Prep& p, double x) {
@@ -722,9 +729,11 @@ struct PeaksModel {
   static constexpr double kFarT = 40.0;
   static __device__ __forceinline__ unsigned tile_mask(const Prep& p, double xlo, double xhi) {
     const double blo = bg_of(p, xlo), bhi = bg_of(p, xhi);
-    const double bmin = blo < bhi ? blo : bhi;
-    const bool usable = p.skip && (bmin > 0.0) && finite_f64(blo) && finite_f64(bhi);
-    const int ef = __builtin_amdgcn_frexp_exp(bmin);  // bmin in [2^(ef-1), 2^ef)
+    const bool bpos = blo > 0.0 && bhi > 0.0, bneg = blo < 0.0 && bhi < 0.0;
+    const double lb = fabs(blo) < fabs(bhi) ? fabs(blo) : fabs(bhi);
+    // known: |f| >= lb holds for the running f of every point of the window
+    bool known = p.skip && (bpos || bneg) && finite_f64(blo) && finite_f64(bhi);
+    const int ef = __builtin_amdgcn_frexp_exp(lb);  // lb in [2^(ef-1), 2^ef)
     unsigned m = 0;
     bool guard = false;
 #pragma unroll
@@ -739,8 +748,10 @@ struct PeaksModel {
       guard = guard || !(far || in);
       const double kd = __builtin_fma(-tmin, tmin, p.K.magic);
       const int kmin = (int)__double_as_longlong(kd) >> 8;  // (meaningful when `in`)
-      const bool noop = far || (usable && in && same_side && (kmin <= ef + p.thr[k]));
+      const bool noop = far || (known && in && same_side && (kmin <= ef + p.thr[k]));
       m |= noop ? 0u : (1u << k);
+      // an evaluated peak: the bound survives a non-negative addend to a positive f only
+      known = known && (noop || (bpos && p.A[k] >= 0.0));
     }
     // per LANE: sweep() gives each lane the range of a different window (64 per pass) and later
     // broadcasts the window's word with readlane, so the tests in eval() are scalar branches
@@ -774,14 +785,13 @@ struct PeaksModel {
       const double ta = fabs(__builtin_fma(fn.xmin, p.iw[k], p.mu[k]));
       const double tb = fabs(__builtin_fma(fn.xmax, p.iw[k], p.mu[k]));
       fast = fast && (ta < kFastT) && (tb < kFastT);
-      // |A_k| < 2^ea; a negative, infinite or NaN amplitude switches the relative rule off
-      skip = skip && (p.A[k] >= 0.0) && finite_f64(p.A[k]);
+      // |A_k| < 2^ea; an infinite or NaN amplitude switches skipping off
       afin = afin && finite_f64(p.A[k]);
       p.thr[k] = __builtin_amdgcn_readfirstlane(-__builtin_amdgcn_frexp_exp(p.A[k]) - 56);
     }
     p.fast = fast;
     // (with kHasSkip the fast / guarded choice is made per window, tile_mask; without it per step)
-    p.skip = skip && kHasSkip;
+    p.skip = skip && afin && kHasSkip;
     p.afin = afin;
     p.K.pin();
     unsigned rmask = 0;

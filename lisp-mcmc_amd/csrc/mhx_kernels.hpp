@@ -106,22 +106,27 @@ __device__ __forceinline__ void tile_dma(const FnDesc& f, int64_t t, GroupLds& l
 // only one or two waves are left to fill the SIMD's issue slots, which one or two dependent
 // fp64 streams cannot.  Priority by PROGRESS evens that out: a wave enters a tile at priority
 // 3 and drops one level per quarter of the tile, so whoever is behind goes first and the four
-// reach the barrier within a quarter tile of one another.  (s_setprio takes an immediate: `it`
-// is a constant after unrolling, `sec` is not.)
+// reach the barrier within a quarter tile of one another.  (s_setprio takes an immediate: `it` is a constant
+// after unrolling, `sec` is not.)
 template <int NIT, int NIN>
 __device__ __forceinline__ void tile_prio(int sec, int it) {
 #ifndef MHX_NO_TILE_PRIO  // (build knob for A/B measurements)
-  constexpr int step = NIT >= 4 ? NIT / 4 : 1;
-  static_assert(NIN % step == 0, "a section starts on a priority step");
-  if (it % step == 0) {
-    const int q = (sec * NIN + it) / step;
-    switch (q) {
-      case 0: __builtin_amdgcn_s_setprio(3); break;
-      case 1: __builtin_amdgcn_s_setprio(2); break;
-      case 2: __builtin_amdgcn_s_setprio(1); break;
-      default: __builtin_amdgcn_s_setprio(0); break;
-    }
-  }
+#ifndef MHX_PRIO_LADDER
+#define MHX_PRIO_LADDER 0
+#endif
+  const int g = sec * NIN + it;  // iteration of the tile (`it` is a constant after unrolling)
+#if MHX_PRIO_LADDER
+  // (levels after 1/2, 3/4 and 7/8 of the tile - a shorter last level: no gain on config 2 and
+  // -5 % on config 3 against quarters, measured)
+  constexpr int b1 = NIT / 2, b2 = NIT >= 4 ? 3 * NIT / 4 : NIT, b3 = NIT >= 8 ? 7 * NIT / 8 : NIT;
+#else
+  constexpr int b1 = NIT / 4, b2 = NIT / 2, b3 = 3 * NIT / 4;  // a level per quarter of the tile
+#endif
+  static_assert(NIT >= 2 && (NIN & (NIN - 1)) == 0, "sections of 2^k iterations");
+  if (g == 0) __builtin_amdgcn_s_setprio(3);
+  else if (g == b1) __builtin_amdgcn_s_setprio(2);
+  else if (g == b2) __builtin_amdgcn_s_setprio(1);
+  else if (g == b3) __builtin_amdgcn_s_setprio(0);
 #endif
 }
 
