@@ -537,7 +537,6 @@ struct PeaksModel {
     // uniform-grid recurrence (below): per peak -2 D, -D^2 and 2^(-2 D^2), D = the step of t from
     // one point of a lane to its next (64 grid points on); rec: usable this step
     double rm2d[NPK], rnd2[NPK], rq[NPK];
-    double gH;       // FnDesc::grid_H (uniform)
     unsigned rmask;  // bit k: peak k goes by the recurrence this step
     // ... and when EVERY peak does, so does a constant or linear background (b(x + 64 h) =
     // b(x) + 64 h b1, re-seeded with the peaks): such a step never reads x beyond the seeds, which
@@ -611,13 +610,10 @@ struct PeaksModel {
         double t[2], v[2];
         const bool on[2] = {true, true};
         t[0] = __builtin_fma(x0, p.iw[k], p.mu[k]);
-        // -2 D and -D^2 formed here from D = 64 h iw (the same products prepare() forms for the
-        // <= 2-peak models): kept per peak they were ten more scalars than the register file
-        // has, reloaded from scratch at every seed (config 3)
-        double gh = p.gH;
-        asm volatile("" : "+s"(gh));  // (formed HERE: hoisted out of the tile loop they spill again)
-        const double dl = gh * p.iw[k];
-        t[1] = __builtin_fma(-2.0 * dl, t[0], -(dl * dl));
+        // (forming -2 D and -D^2 here from D = 64 h iw instead of keeping them per peak takes the
+        // kernel's scratch from 224 to 188 B per lane and config 3 from 7.70e5 to 7.31e5
+        // chain-steps/s: the reloads at the seeds are cheaper than the arithmetic - measured)
+        t[1] = __builtin_fma(p.rm2d[k], t[0], p.rnd2[k]);
         mexp2_negsq_batch<2, true>(t, on, p.K, v);
         rs.g[k] = v[0];
         rs.r[k] = v[1];
@@ -802,11 +798,10 @@ struct PeaksModel {
     p.afin = afin;
     p.K.pin();
     unsigned rmask = 0;
-    p.gH = uniform_f64(fn.grid_H);
 #pragma unroll
     for (int k = 0; k < NPK; ++k) {
       const double dl = fn.grid_H * p.iw[k];  // D_k
-      p.rm2d[k] = uniform_f64(-2.0 * dl);     // (read by rec_seed for NPK <= 2 only)
+      p.rm2d[k] = uniform_f64(-2.0 * dl);
       p.rnd2[k] = uniform_f64(-(dl * dl));
       p.rq[k] = uniform_f64(mexp2(2.0 * p.rnd2[k]));
       const bool ok = kHasRec && (fast || kHasSkip) && fn.grid_H != 0.0 &&
