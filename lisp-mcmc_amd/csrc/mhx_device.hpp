@@ -705,11 +705,13 @@ struct PeaksModel {
   // What the rule needs is a lower bound on |f| at the moment peak k is added, and the sign of
   // nothing: while every earlier peak of the window was itself left out, f IS the background,
   // whose magnitude over the window is at least lb = min(|bg(xlo)|, |bg(xhi)|) when both ends
-  // have the same sign - negative backgrounds and negative amplitudes included; after a peak has
-  // been evaluated the bound survives only if the background is positive and that peak's
-  // amplitude is >= 0 (f can only have grown).  Otherwise the later peaks of that window are
-  // evaluated.  Preconditions: 1 <= NBG <= 2, every amplitude finite, bg finite and of one
-  // sign at both ends of the window, the window on the table-exp path.
+  // have the same sign - negative backgrounds and negative amplitudes included.  An evaluated
+  // peak changes f by less than 2^(ea + kmin + 1): if the background is positive and every
+  // evaluated amplitude so far was >= 0, f has only grown and lb still holds; otherwise that
+  // much comes off the bound (|f + a| >= |f| - |a|; the roundings of f and of the bound are
+  // far inside the factor 2 the test keeps in hand), and once it reaches 0 the later peaks of
+  // the window are evaluated.  Preconditions: 1 <= NBG <= 2, every amplitude finite, bg finite
+  // and of one sign at both ends of the window, the window on the table-exp path.
   static constexpr bool kHasSkip = !LORENTZ && NBG >= 1 && NBG <= 2 && NPK <= 30;
   static constexpr int kPeaks = NPK;
   static __device__ __forceinline__ double bg_of(const Prep& p, double x) {
@@ -734,9 +736,10 @@ struct PeaksModel {
     const double blo = bg_of(p, xlo), bhi = bg_of(p, xhi);
     const bool bpos = blo > 0.0 && bhi > 0.0, bneg = blo < 0.0 && bhi < 0.0;
     const double lb = fabs(blo) < fabs(bhi) ? fabs(blo) : fabs(bhi);
-    // known: |f| >= lb holds for the running f of every point of the window
-    bool known = p.skip && (bpos || bneg) && finite_f64(blo) && finite_f64(bhi);
-    const int ef = __builtin_amdgcn_frexp_exp(lb);  // lb in [2^(ef-1), 2^ef)
+    // lbr: a lower bound on |f| for the running f of every point of the window (0: none);
+    // mono: f has only grown from a positive background so far, so bg's bound still holds
+    double lbr = (p.skip && (bpos || bneg) && finite_f64(blo) && finite_f64(bhi)) ? lb : 0.0;
+    bool mono = bpos;
     unsigned m = 0;
     bool guard = false;
 #pragma unroll
@@ -751,10 +754,19 @@ struct PeaksModel {
       guard = guard || !(far || in);
       const double kd = __builtin_fma(-tmin, tmin, p.K.magic);
       const int kmin = (int)__double_as_longlong(kd) >> 8;  // (meaningful when `in`)
-      const bool noop = far || (known && in && same_side && (kmin <= ef + p.thr[k]));
+      const int ef = __builtin_amdgcn_frexp_exp(lbr);       // lbr in [2^(ef-1), 2^ef)
+      const bool noop =
+          far || ((lbr > 0.0) && in && same_side && (kmin <= ef + p.thr[k]));
       m |= noop ? 0u : (1u << k);
-      // an evaluated peak: the bound survives a non-negative addend to a positive f only
-      known = known && (noop || (bpos && p.A[k] >= 0.0));
+      // an evaluated peak moves f by less than 2^(ea + kmin + 1) (by less than 2^(ea + 1) when
+      // its centre lies inside the window): a non-negative addend to a positive f leaves bg's
+      // bound alone, anything else takes that much off it
+      if (!noop && !(mono && p.A[k] >= 0.0)) {
+        mono = false;
+        const int km = (same_side && in) ? kmin : 0;
+        const double left = lbr - ldexp(1.0, km - p.thr[k] - 55);
+        lbr = left > 0.0 ? left : 0.0;  // (NaN: 0)
+      }
     }
     // per LANE: sweep() gives each lane the range of a different window (64 per pass) and later
     // broadcasts the window's word with readlane, so the tests in eval() are scalar branches

@@ -37,10 +37,12 @@ def adversarial_two_peak(theta_star, n, seed):
     rng = np.random.default_rng(seed)
     th = np.tile(theta_star, (n, 1))
     # columns: b0 b1 A1 mu1 w1 A2 mu2 w2
-    th[:, 0] = rng.choice([0.5, 1e-3, 1e-12, 0.0, -0.2, 40.0, 1e8], n)      # background level
+    th[:, 0] = rng.choice([0.5, 1e-3, 1e-12, 0.0, -0.2, -1e-3, -40.0, 40.0, 1e8], n)  # background level
     th[:, 1] = rng.choice([0.3, 0.0, -0.49, -0.6, 5.0, -1e-3], n)           # slope: bg may cross 0
-    th[:, 2] = rng.choice([1.0, 0.0, -1.0, 1e-30, 1e30, 1e300, 3e-310], n)  # amplitudes
-    th[:, 5] = rng.choice([0.7, 0.0, -0.7, 1e-300, 1e12], n)
+    # amplitudes of either sign, from far below to far above the background (the rule's lower
+    # bound on |f| loses what an evaluated peak of the wrong sign can take off it)
+    th[:, 2] = rng.choice([1.0, 0.0, -1.0, 0.3, -0.3, 1e-30, 1e30, 1e300, 3e-310], n)
+    th[:, 5] = rng.choice([0.7, 0.0, -0.7, 0.05, -0.05, 1e-300, 1e12], n)
     th[:, 3] = rng.uniform(-0.5, 1.5, n)                                    # centres in and out of range
     th[:, 6] = rng.uniform(-0.5, 1.5, n)
     th[:, 4] = 10.0 ** rng.uniform(-4, 0.5, n) * rng.choice([1, 1, 1, -1], n)  # widths, some negative
@@ -57,7 +59,7 @@ def test_two_peak_logposts_identical_with_and_without_skipping(mhx, n, order):
         p = np.random.default_rng(1).permutation(n)
         s.data[0] = (x[p], y[p], sig[p], lik)
     a, b = both_engines(mhx, s, 1)
-    th = adversarial_two_peak(s.theta_star, 300, seed=n)
+    th = adversarial_two_peak(s.theta_star, 600, seed=n)
     with np.errstate(all="ignore"):
         ga, pa = a.logpost(th, parts=True)
         gb, pb_ = b.logpost(th, parts=True)
