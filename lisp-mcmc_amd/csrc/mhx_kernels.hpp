@@ -33,6 +33,7 @@ struct GroupLds {
 #ifdef MHX_X_TIMING  // (measurement build: cycles per phase of an iteration, see MHX_TIM)
   unsigned long long tim[kWavesPerGroup][8], tlast[kWavesPerGroup];
 #endif
+  int vote[4];  // "is any chain of the workgroup still running": three flags used in turn
   double park[kWavesPerGroup][12];  // a ChainPark per wave: the chain's scalars during a sweep
   // the chain's position theta while a stepping kernel runs, for d <= kCurParams (beyond that it
   // is re-read from HBM): two L2 round trips less per iteration of a latency-bound single walker
@@ -51,6 +52,7 @@ __device__ __forceinline__ void lds_tables_begin() {
 }
 __device__ __forceinline__ void lds_begin(GroupLds& lds) {
   if (threadIdx.x == 0) lds.resident = 0;
+  if (threadIdx.x < 4) lds.vote[threadIdx.x] = 0;
   lds_tables_begin();
   __syncthreads();
 }
@@ -66,7 +68,7 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 // cycles since the wave's previous mark on phase k; k_adaptive leaves the eight sums in the
 // chain's most-likely-parameters row.  Not part of the product build.
 #ifdef MHX_X_TIMING
-#define MHX_TIM(LDS, K)                                                      \
+#define MHX_TIM_(LDS, K)                                                     \
   do {                                                                       \
     const unsigned long long now_ = __builtin_readcyclecounter();            \
     if (lane_id() == 0) {                                                    \
@@ -74,8 +76,19 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
       (LDS).tlast[wave_in_group()] = now_;                                   \
     }                                                                        \
   } while (0)
+#endif
+// -DMHX_X_TIMING=1: the phases of the sweep (MHX_TIM); =2: the steps of the controller (MHX_TIMC:
+// 0 vote + shut-down test, 1 random numbers, 2 proposal, 3 the whole log-posterior, 4 accept,
+// 5 :add-step, 6 annealing + adaptation test, 7 loop overhead)
+#if defined(MHX_X_TIMING) && MHX_X_TIMING + 0 == 2
+#define MHX_TIM(LDS, K) do { } while (0)
+#define MHX_TIMC(LDS, K) MHX_TIM_(LDS, K)
+#elif defined(MHX_X_TIMING)
+#define MHX_TIM(LDS, K) MHX_TIM_(LDS, K)
+#define MHX_TIMC(LDS, K) do { } while (0)
 #else
 #define MHX_TIM(LDS, K) do { } while (0)
+#define MHX_TIMC(LDS, K) do { } while (0)
 #endif
 
 // Tile t of every array of function f -> LDS buffer `buf`, by LDS-DMA (global_load_lds_dwordx4:
@@ -645,13 +658,30 @@ __device__ __forceinline__ double bound_penalty(double p, double lo, double hi) 
   const double m = a < b ? a : b;
   return -1e10 * (dexp(m * 1e-5) - 1.0);
 }
+// bounds-total of one block (M:361-364): the terms in the block's order.  Lane i looks at bound
+// i (one round trip to the descriptor for all of them instead of one per bound: 8 bounds cost
+// 3 k cycles one after the other, and BASELINE config 4 lists 32 of them for each of its 8
+// functions); when no lane finds its parameter outside, every term is +0 and so is the sum;
+// otherwise the lanes' terms are added in index order, as the loop over the list did.
 __device__ __forceinline__ double logprior_fn(const FnDesc& f, const double* theta) {
+  const int l = lane_id();
+  const int nb = __builtin_amdgcn_readfirstlane(f.n_bounds);
+  static_assert(MHX_MAX_BOUNDS <= kWave, "one lane per bound");
+  double p = 0.0, lo = 0.0, hi = 0.0;
+  bool out = false;
+  if (l < nb) {
+    const int ix = f.bidx[l];
+    p = ix >= 0 ? theta[ix] : 0.0;  // (getf params key 0d0) M:353
+    lo = f.blo[l];
+    hi = f.bhi[l];
+    out = !(lo < p && p < hi);
+  }
+  if (__builtin_amdgcn_readfirstlane((int)(__ballot(out) != 0ull)) == 0) return 0.0;
+  const double b = out ? bound_penalty(p, lo, hi) : 0.0;
   double acc = 0.0;
-  for (int i = 0; i < f.n_bounds; ++i) {
-    const int ix = f.bidx[i];
-    const double v = ix >= 0 ? theta[ix] : 0.0;  // (getf params key 0d0) M:353
-    const double b = bound_penalty(v, f.blo[i], f.bhi[i]);
-    acc = i == 0 ? b : acc + b;
+  for (int i = 0; i < nb; ++i) {
+    const double bi = readlane_f64(b, i);
+    acc = i == 0 ? bi : acc + bi;
   }
   return acc;
 }
@@ -1017,20 +1047,24 @@ struct ChainRegs {
 // uniform drawn for the outstanding proposal): 96 bytes, written by lane 0, read back by
 // every lane (one address: a broadcast) and returned to scalar registers
 struct ChainPark {
-  double prob0, best_prob, T, u;
+  double prob0, best_prob, T, u, t_next;
   int64_t nh, length, age, loop_i, reset_index;
   uint64_t draw;
   int shutting, status;
 };
-__device__ __forceinline__ void chain_park(ChainPark& slot, const ChainRegs& r, double u) {
+__device__ __forceinline__ void chain_park(ChainPark& slot, const ChainRegs& r, double u,
+                                           double t_next) {
   if (lane_id() == 0) {
     slot.prob0 = r.prob0; slot.best_prob = r.best_prob; slot.T = r.T; slot.u = u;
+    slot.t_next = t_next;
     slot.nh = r.nh; slot.length = r.length; slot.age = r.age; slot.loop_i = r.loop_i;
     slot.reset_index = r.reset_index; slot.draw = r.draw;
     slot.shutting = r.shutting; slot.status = r.status;
   }
 }
-__device__ __forceinline__ void chain_unpark(const ChainPark& slot, ChainRegs& r, double& u) {
+__device__ __forceinline__ void chain_unpark(const ChainPark& slot, ChainRegs& r, double& u,
+                                             double& t_next) {
+  t_next = uniform_f64(slot.t_next);
   r.prob0 = uniform_f64(slot.prob0);
   r.best_prob = uniform_f64(slot.best_prob);
   r.T = uniform_f64(slot.T);
@@ -1084,10 +1118,19 @@ __device__ __forceinline__ void chain_store(const ChainState& S, int64_t c, int 
 __device__ __forceinline__ double propose(const double* L, int d, double zv, double th) {
   const int l = lane_id();
   double mini = 0.0;
-  for (int j = 0; j < d; ++j) {
-    const double zj = readlane_f64(zv, j);
-    const double lij = l < d ? L[l * d + j] : 0.0;
-    mini = mini + lij * zj;
+  // eight elements of the lane's row at a time, all loads before the first use: one round trip
+  // to L per eight columns instead of one per column (d = 8: 5 k cycles -> 1)
+  for (int j0 = 0; j0 < d; j0 += 8) {
+    double lv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lv[q] = (l < d && j0 + q < d) ? L[l * d + j0 + q] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (j0 + q < d) {  // (uniform; a term is added only where the list had one)
+        const double zj = readlane_f64(zv, j0 + q);
+        mini = mini + lv[q] * zj;
+      }
+    }
   }
   return mini + th;
 }
@@ -1223,6 +1266,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
 
   for (int64_t it = 0; SPLIT || it < max_iters; ++it) {
     MHX_TIM(lds, 6);
+    MHX_TIMC(lds, 7);
     const int l = lane_id();  // (formed per iteration: see lane_id())
     int d_it = P.d;  // likewise the parameter count: what the cold code derives from it (the
     asm volatile("" : "+s"(d_it));  // reciprocal behind e / d ...) is formed where it is used
@@ -1272,7 +1316,18 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     }
     // (the vote is the same in every lane; as a scalar it keeps the loop's exit - and so every
     // counter of the chain that lives across it - out of the vector registers)
-    if (!__builtin_amdgcn_readfirstlane(__syncthreads_or(running ? 1 : 0))) break;
+    // One barrier and a flag per iteration (the library's __syncthreads_or is a workgroup
+    // reduction with two): a running wave raises flag it % 3, everybody reads it after the
+    // barrier, and the flag of iteration it + 2 - last read before the previous barrier, next
+    // written after the next one - is lowered.
+    {
+      const int vp = (int)(it % 3);
+      if (running && l == 0) lds.vote[vp] = 1;
+      __syncthreads();
+      const int any = __builtin_amdgcn_readfirstlane(*(volatile int*)&lds.vote[vp]);
+      if (threadIdx.x == 0) lds.vote[(vp + 2) % 3] = 0;
+      if (!any) break;
+    }
     if (running) {
       if (!plain) {
         // M:905-917
@@ -1295,11 +1350,14 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
         }
       }
       // M:918 walker-take-step: proposal
+      MHX_TIMC(lds, 0);
       const double rv = rng_lane_value(S.seed, gchain, r.draw, d);
       r.draw++;
       u = readlane_f64(rv, 63);
+      MHX_TIMC(lds, 1);
       thp = propose(Lc, d, rv, cur_in_lds ? (l < d ? lds.cur[w][l] : 0.0) : chain_theta(S, c, d));
       if (l < d) lds.prop[w][l] = thp;
+      MHX_TIMC(lds, 2);
     }
     if constexpr (SPLIT) {  // hand the proposal to the sweep launch and stop here
       if (running) {
@@ -1319,17 +1377,23 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     static_assert(sizeof(ChainPark) <= sizeof(lds.park[0]), "ChainPark slot");
     ChainPark& slot = *reinterpret_cast<ChainPark*>(lds.park[w]);
     MHX_TIM(lds, 0);
+    // the temperature the annealing step below will set (M:920-921), fetched now: the round
+    // trip to the schedule overlaps the sweep instead of following it
+    double t_next = r.T;
+    if (running && !plain && !r.shutting && r.loop_i < R.temp_steps)
+      t_next = uniform_f64(R.temps[r.loop_i - R.temps_first]);
 #ifndef MHX_NO_PARK  // (build knob for A/B measurements)
-    if constexpr (!SPLIT) chain_park(slot, r, u);
+    if constexpr (!SPLIT) chain_park(slot, r, u, t_next);
 #endif
     if constexpr (SPLIT)
       prob1 = split_logpost<Spec>(P, S, c, running, lds, w, &ll, &lp);
     else
       prob1 = group_logpost<Spec>(P, running, lds, w, &ll, &lp);
 #ifndef MHX_NO_PARK
-    if constexpr (!SPLIT) chain_unpark(slot, r, u);
+    if constexpr (!SPLIT) chain_unpark(slot, r, u, t_next);
 #endif
     MHX_TIM(lds, 7);
+    MHX_TIMC(lds, 3);
     // the butterfly leaves the same bits in every lane: scalar from here on, and with it the
     // accept decision and every counter of the chain changed under it
     prob1 = uniform_f64(prob1);
@@ -1344,10 +1408,12 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
       const bool take =
           __builtin_amdgcn_readfirstlane((int)mh_accept(prob1, r.prob0, r.T, u)) != 0;
       if (take) r.prob0 = prob1;
+      MHX_TIMC(lds, 4);
       const double th_now = take ? (l < d ? lds.prop[w][l] : 0.0)
                                  : (cur_in_lds ? (l < d ? lds.cur[w][l] : 0.0) : chain_theta(S, c, d));
       if (take && cur_in_lds && l < d) lds.cur[w][l] = th_now;
       add_step(S, c, d, r, th_now, take);
+      MHX_TIMC(lds, 5);
     }
     if (plain) {
       r.loop_i++;
@@ -1355,7 +1421,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     }
     const int64_t i = r.loop_i;
     // annealing M:920-921
-    if (!r.shutting && i < R.temp_steps) r.T = uniform_f64(R.temps[i - R.temps_first]);
+    if (!r.shutting && i < R.temp_steps) r.T = t_next;
     // cleaning M:923-927 (:keep-walks only shortens what :take can see)
     if (R.has_mwl && i == r.reset_index) {
       if (r.length > R.mwl) {
@@ -1408,6 +1474,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
         }
       }
     }
+    MHX_TIMC(lds, 6);
     if (r.status == MHX_CHAIN_RUNNING) r.loop_i++;
   }
   if (valid) {
@@ -1415,7 +1482,12 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     chain_store(S, c, d, r);
     if (l == 0 && r.age != age0) atomicAdd(S.step_counter, (unsigned long long)(r.age - age0));
 #ifdef MHX_X_TIMING
-    if (l < 8 && l < d) S.best_theta[c * d + l] = (double)lds.tim[w][l];
+    if (l < 8 && l < d) {  // (d < 8: the last slot takes the rest)
+      unsigned long long v = lds.tim[w][l];
+      if (l == d - 1)
+        for (int k = d; k < 8; ++k) v += lds.tim[w][k];
+      S.best_theta[c * d + l] = (double)v;
+    }
 #endif
   }
 }
