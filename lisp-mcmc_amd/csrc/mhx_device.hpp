@@ -193,18 +193,22 @@ __device__ __forceinline__ unsigned long long bits53(uint32_t a, uint32_t b) {
 // correctly rounded sqrt (IEEE), so z matches the host's sqrt bit for bit
 __device__ __forceinline__ double ieee_sqrt(double x) { return __dsqrt_rn(x); }
 
-// lane j < d returns z_j; lane 63 returns the accept uniform u in (0,1]; other lanes junk
+// lane j < d returns z_j; lane 63 returns the accept uniform u in (0,1]; other lanes junk.
+// *log_u1: det_log of the lane's first uniform - in lane 63 the log u of the accept test
+// (M:1092), which the Box-Muller transform of the other lanes computes in passing.
 __device__ __forceinline__ double rng_lane_value(uint64_t seed, uint64_t gchain, uint64_t draw,
-                                                 int d) {
+                                                 int d, double* log_u1 = nullptr) {
   int l = lane_id();
   uint32_t slot = (l == 63) ? 0xFFFFFFFFu : (uint32_t)l;
   uint32_t r[4];
   philox4x32_10((uint32_t)gchain, slot, (uint32_t)draw, (uint32_t)(draw >> 32), (uint32_t)seed,
                 (uint32_t)(seed >> 32), r);
   double u1 = (double)(bits53(r[0], r[1]) + 1ULL) * 0x1p-53;
+  const double lg = det_log(u1);
+  if (log_u1) *log_u1 = lg;
   if (l == 63) return u1;
   double u2 = (double)bits53(r[2], r[3]) * 0x1p-53;
-  double rad = ieee_sqrt(-2.0 * det_log(u1));
+  double rad = ieee_sqrt(-2.0 * lg);
   (void)d;
   return rad * det_cos2pi(u2);
 }

@@ -41,6 +41,9 @@ struct GroupLds {
   int resident;  // 1: tile 0 of the problem's only function sits in tiles[0] (FnDesc::solo)
 };
 constexpr unsigned kSweepLdsBytes = sizeof(LdsHead);  // dynamic LDS of k_split_sweep
+// 160 KiB of LDS per CU: one workgroup of the 16-wave family, TWO of the 8-wave family
+static_assert(sizeof(GroupLds) * (kWavesPerGroup <= 8 ? 2 : 1) <= 160 * 1024,
+              "GroupLds no longer fits the workgroups per CU its kernel family counts on");
 static_assert(__builtin_offsetof(GroupLds, head) == 0, "the tables must lead the dynamic LDS");
 
 // every kernel that sweeps starts with this (LDS comes up uninitialised)
@@ -1166,6 +1169,10 @@ __device__ __forceinline__ double chain_theta(const ChainState& S, int64_t c, in
 __device__ __forceinline__ bool mh_accept(double prob1, double prob0, double T, double u) {
   return (prob1 > prob0) || ((prob1 - prob0) / T > det_log(u));
 }
+// ... with det_log(u) already at hand (the fused kernel: rng_lane_value)
+__device__ __forceinline__ bool mh_accept_log(double prob1, double prob0, double T, double log_u) {
+  return (prob1 > prob0) || ((prob1 - prob0) / T > log_u);
+}
 
 template <class Spec>
 __global__ __launch_bounds__(kThreads) void k_step_injected(
@@ -1351,9 +1358,11 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
       }
       // M:918 walker-take-step: proposal
       MHX_TIMC(lds, 0);
-      const double rv = rng_lane_value(S.seed, gchain, r.draw, d);
+      double lg;
+      const double rv = rng_lane_value(S.seed, gchain, r.draw, d, &lg);
       r.draw++;
-      u = readlane_f64(rv, 63);
+      // (the fused kernel carries log u to the accept test, split mode u itself)
+      u = SPLIT ? readlane_f64(rv, 63) : readlane_f64(lg, 63);
       MHX_TIMC(lds, 1);
       thp = propose(Lc, d, rv, cur_in_lds ? (l < d ? lds.cur[w][l] : 0.0) : chain_theta(S, c, d));
       if (l < d) lds.prop[w][l] = thp;
@@ -1406,7 +1415,9 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
       // the proposal is still in the wave's LDS slot (nothing of it was kept in registers
       // across the sweep)
       const bool take =
-          __builtin_amdgcn_readfirstlane((int)mh_accept(prob1, r.prob0, r.T, u)) != 0;
+          __builtin_amdgcn_readfirstlane(
+              (int)(SPLIT ? mh_accept(prob1, r.prob0, r.T, u)
+                          : mh_accept_log(prob1, r.prob0, r.T, u))) != 0;
       if (take) r.prob0 = prob1;
       MHX_TIMC(lds, 4);
       const double th_now = take ? (l < d ? lds.prop[w][l] : 0.0)
