@@ -207,14 +207,29 @@ def main():
         # synchronisation, no Python in the data path.  torch.distributed only carries the 128-byte
         # communicator id from rank 0 to the others (and the barriers / max of the contract).
         collective = "libmhx RCCL communicator (ncclAllReduce on the engine's stream)"
-        try:
-            uid = [mhx.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            e.comm_init_rank(uid[0], rank, world)
-        except Exception as ex:  # librccl not loadable by libmhx: the torch.distributed hook instead
+        # (every rank takes the same branch: rank 0's failure to make an id travels in the
+        # broadcast, a failure to join the communicator through an all-reduced flag)
+        uid, why = [None], ""
+        if rank == 0:
+            try:
+                uid = [mhx.comm_unique_id()]
+            except Exception as ex:
+                uid = [("failed", str(ex))]
+        dist.broadcast_object_list(uid, src=0)
+        ok = isinstance(uid[0], (bytes, bytearray))
+        if ok:
+            try:
+                e.comm_init_rank(uid[0], rank, world)
+            except Exception as ex:
+                ok, why = False, str(ex)
+        else:
+            why = uid[0][1]
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:  # librccl not usable by libmhx somewhere: the torch.distributed hook
             from lisp_mcmc_amd import distributed as mdist
             e.set_allreduce(mdist.torch_allreduce_hook(dist), device_buffer=True)
-            collective = "torch.distributed all_reduce hook (libmhx RCCL unavailable: %s)" % ex
+            collective = "torch.distributed all_reduce hook (libmhx RCCL unavailable: %s)" % (why or "on another rank")
     # per-chain start: theta* (1 + 0.01 N(0,1)), keyed by GLOBAL chain id
     rng = np.random.Generator(np.random.Philox(key=0x5EED0002 + rank))
     th0 = spec.theta_star[None, :] * (1.0 + 0.01 * rng.standard_normal((chains, spec.d)))

@@ -249,7 +249,9 @@ int mhx_request_stop(mhx_engine* e);
 
 /* Multi-rank pooled adaptation through a caller-supplied sum (MPI, a test stub ...): installs the
  * all-reduce used every adaptation tick.  The native path is RCCL: mhx_comm_init_rank (one
- * process per GPU) or mhx_group_create (one process, several GPUs) below. */
+ * process per GPU) or mhx_group_create (one process, several GPUs) below.  A hook installed
+ * AFTER mhx_comm_init_rank replaces that communicator (it is destroyed): every rank must then
+ * exchange through its hook. */
 int mhx_set_allreduce(mhx_engine* e, mhx_allreduce_fn fn, void* ctx, int wants_device_buffer);
 
 /* ---- native RCCL (librccl.so is loaded on first use; MHX_ECOMM when it is absent) ----------

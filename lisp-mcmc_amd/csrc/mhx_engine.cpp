@@ -1377,6 +1377,14 @@ int mhx_request_stop(mhx_engine* e) {
 
 int mhx_set_allreduce(mhx_engine* e, mhx_allreduce_fn fn, void* ctx, int wants_device_buffer) {
   if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  // a hook set after mhx_comm_init_rank replaces the library's own communicator (which would
+  // otherwise take precedence in pool_refresh): the caller has decided that every rank exchanges
+  // through the hook
+  if (fn && e->comm) {
+    if (e->comm_owned && rccl().ok) (void)rccl().CommDestroy(e->comm);
+    e->comm = nullptr;
+    e->comm_owned = false;
+  }
   e->allreduce = fn;
   e->allreduce_ctx = ctx;
   e->allreduce_device = wants_device_buffer;

@@ -129,6 +129,29 @@ def test_native_rccl_all_reduce_on_one_rank(mhx):
     rccl.close()
 
 
+def test_a_hook_set_after_the_communicator_replaces_it(mhx):
+    """bench.py's fall-back: when some rank cannot join the RCCL communicator, EVERY rank switches
+    to the host hook - also the ones that did join (mhx_set_allreduce destroys the communicator)"""
+    s = pb.two_peak(n=2000, seed=6)
+    C_ = 32
+    th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=8)
+    e = s.engine(mhx, C_, seed=12, adapt_mode=mhx.capi.ADAPT_POOLED)
+    e.comm_init_rank(mhx.comm_unique_id(), 0, 1)
+    calls = []
+
+    def hook(buf, n, dev):
+        calls.append((n, dev))
+        return 0
+    e.set_allreduce(hook, device_buffer=False)
+    plain = s.engine(mhx, C_, seed=12, adapt_mode=mhx.capi.ADAPT_POOLED)
+    a, b = _walk(plain, th0, 700), _walk(e, th0, 700)
+    assert len(calls) == 3 and calls[0] == (1 + 8 + 64, 0)
+    for k in ("theta", "logpost", "age"):
+        assert np.array_equal(a[k], b[k]), k
+    e.close()
+    plain.close()
+
+
 def test_take_step_and_get_chain(mhx, orc):
     """(walker-take-step w :l-matrix L) with the device's randomness = one iteration of
     walker-many-steps (M:852-853); mhx_get_chain = one row of mhx_get_state"""
