@@ -464,6 +464,11 @@ __device__ __forceinline__ double tlog(double x, lds_cdptr_t tab, double A3 = kT
 // bit for bit: k = rint(x log2 e), r = x - k ln2 (hi/lo), degree-13 Taylor in Horner form.
 // < 1 ulp for |x| < 700.  Used by the bounds prior (M:360), off the hot loop.
 __device__ __forceinline__ double dexp(double x) {
+  // beyond the range of a double the answer is decided here (inf, 0, NaN for NaN): the
+  // reduction below is meaningless there - it once answered -inf for e^(1e25), a bound
+  // violated by 1e30, and the oracle's restatement something else again
+  if (!(x < 0x1.62e42fefa39efp+9)) return x != x ? x : __builtin_inf();
+  if (x < -745.2) return 0.0;
   const double MAGIC = 0x1.8p52;
   const double kd = __builtin_fma(x, 1.4426950408889634074, MAGIC);
   const double kf = kd - MAGIC;

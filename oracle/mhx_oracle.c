@@ -600,6 +600,9 @@ static double mir_exp2_negsq_safe(double t) {
 }
 
 static double mir_dexp(double x) {
+  /* csrc/mhx_device.hpp, dexp: beyond the range of a double the answer is decided up front */
+  if (!(x < 0x1.62e42fefa39efp+9)) return x != x ? x : INFINITY;
+  if (x < -745.2) return 0.0;
   const double MAGIC = 0x1.8p52;
   double kd = fma(x, 1.4426950408889634074, MAGIC);
   double kf = kd - MAGIC;

@@ -52,7 +52,7 @@ def adversarial_two_peak(theta_star, n, seed):
 
 
 @pytest.mark.parametrize("n,order", [(30000, "sorted"), (30000, "shuffled"), (1500, "sorted"), (1024, "sorted")])
-def test_two_peak_logposts_identical_with_and_without_skipping(mhx, n, order):
+def test_two_peak_logposts_identical_with_and_without_skipping(mhx, orc, n, order):
     s = pb.two_peak(n=n, seed=400 + n)
     if order == "shuffled":  # tiles then span the whole x range: nothing can be skipped, nothing may change
         x, y, sig, lik = s.data[0]
@@ -66,6 +66,13 @@ def test_two_peak_logposts_identical_with_and_without_skipping(mhx, n, order):
     assert np.array_equal(ga, gb, equal_nan=True)
     assert np.array_equal(pa, pb_, equal_nan=True)
     assert np.isfinite(ga[:4]).all()
+    # ... and both equal the oracle's restatement of the kernel, which knows nothing of masks but
+    # decides table / guarded exp and "exactly zero over this window" per window on its own
+    op = s.oracle(orc)
+    for i in range(0, 600, 5):
+        with np.errstate(all="ignore"):
+            ref = op.logpost_mirror(th[i])
+        assert ga[i] == ref or (np.isnan(ga[i]) and np.isnan(ref)), (n, order, i, th[i], ga[i], ref)
     a.close()
     b.close()
 
