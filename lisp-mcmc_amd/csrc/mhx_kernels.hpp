@@ -181,14 +181,11 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
   constexpr int kTPW = kPadPoints / kTilePoints;
   const int64_t nw = (nt + kTPW - 1) / kTPW;
   unsigned tile_masks = ~0u;  // lane i: which peaks window (wi & ~63) + i needs (PeaksModel::tile_mask)
-  // (REC) the peaks' running g, r live from one seed to the next: across the tiles of a window
-  // (8-wave family), across the sections of a tile, or within a section
+  // (REC) the peaks' running g, r live from one seed to the next: across the sections of a
+  // window, or within a section
   typedef typename model_rec_state<Model>::type RecState;
   constexpr int kSeedPts = model_seed_steps<Model>::value;  // points of a lane from seed to seed
-  constexpr int kLanePtsPerTile = kTilePoints / kWave;
   static_assert(kSeedPts % 16 == 0 && (kPadPoints / kWave) % kSeedPts == 0, "seeds per window");
-  RecState rs_sweep;
-  (void)rs_sweep;
   (void)nw;
   if (nt == 0) return 0.0;
   // A problem with ONE function of ONE tile (test.lisp's 334 points) walked by a single
@@ -212,13 +209,25 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
     __syncthreads();
   }
   MHX_TIM(lds, 3);
-  for (int64_t t = 0; t < nt; ++t) {
+  // Between the two tiles of a window (8-wave family): everybody is through with tile `tcur`
+  // and the next one has landed; the buffer just read takes the tile after that.
+  auto mid_hook = [&](int64_t tcur, int bufc) {
+#ifndef MHX_NO_TILE_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tcur + 2 < nt) tile_dma<NARR>(f, tcur + 2, lds, bufc, w);
+  };
+  // One pass of this loop is one WINDOW: a tile of the 16-wave family, two tiles of the 8-wave
+  // family (which then always finds the window's first tile in buffer 0, its second in buffer 1).
+  for (int64_t t = 0; t < nt; t += kTPW) {
     const int buf = (int)(t & 1);
-    const int64_t wi = t / kTPW;            // the window this tile belongs to ...
-    const bool wstart = (t % kTPW) == 0;    // ... and whether it opens it
+    const int64_t wi = t / kTPW;  // the window
+    constexpr bool wstart = true;
     (void)wi;
-    (void)wstart;
-    // buffer buf^1 was last read in iteration t-1, which every wave left through the barrier
+    // buffer buf^1 was last read in tile t-1, which every wave left through the barrier; (two
+    // tiles per window: tile t itself was sent for by the previous window's mid_hook)
     if (t + 1 < nt) tile_dma<NARR>(f, t + 1, lds, buf ^ 1, w);
     // Which Gaussian peaks this window needs (those that cannot change any of its sums by even
     // one bit are left out: PeaksModel::tile_mask; exact, so the results do not depend on it),
@@ -293,17 +302,25 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
         static_assert(kTilePoints % (kWave * P) == 0 && NIT % NIN == 0, "whole sections per tile");
         // points of this tile that are data (the rest are neutral pads): short datasets such as
         // test.lisp's 334 points leave most of their only tile unused
-        const int nv = (int)((f.n - gbase) < (int64_t)kTilePoints ? (f.n - gbase) : (int64_t)kTilePoints);
+        constexpr int kWinPoints = kTPW * kTilePoints;
+        const int nv = (int)((f.n - gbase) < (int64_t)kWinPoints ? (f.n - gbase) : (int64_t)kWinPoints);
         RecState rs_tile;
         (void)rs_tile;
+        // the sections of the window: NSEC per tile; the second tile of a window sits one buffer on
+        constexpr int kBufStride = kMaxArrays * kTilePoints;
 #pragma unroll 1
-        for (int sec = 0; sec < NSEC; ++sec) {
-          const int sbase = sec * NIN * P * kWave;  // first tile element of this section
-          if (sbase >= nv) break;
+        for (int ws = 0; ws < kTPW * NSEC; ++ws) {
+          const int tt = ws / NSEC, sec = ws % NSEC;
+          if (kTPW > 1 && tt > 0 && sec == 0) {
+            if (t + tt >= nt) break;
+            mid_hook(t + tt - 1, buf ^ (tt - 1));
+          }
+          const int wb = ws * NIN * P * kWave;  // first point of this section in the window
+          const int sbase = tt * kBufStride + sec * NIN * P * kWave;  // ... and in the buffers
+          if (wb >= nv) break;
           RecState rs_sec;
           (void)rs_sec;
-          RecState& rs = *(kSeedPts > kLanePtsPerTile ? &rs_sweep
-                                                      : (kSeedPts > NIN * P ? &rs_tile : &rs_sec));
+          RecState& rs = *(kSeedPts > NIN * P ? &rs_tile : &rs_sec);
           // (each section starts its own read pipeline: carrying the registers of the next points
           // over the section loop's back edge - one uncovered LDS read per tile less - measured
           // 14 % SLOWER on config 2 and 23 % on config 3)
@@ -326,7 +343,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
           }
 #pragma unroll
           for (int it = 0; it < NIN; ++it) {
-            if (sbase + it * P * kWave >= nv) break;  // uniform: one scalar compare per P points
+            if (wb + it * P * kWave >= nv) break;  // uniform: one scalar compare per P points
             tile_prio<NIT, NIN>(sec, it);
             double xn[P], yn[P], wn[P], cn[P];
 #pragma unroll
@@ -355,7 +372,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
                 // seeded at the lane's first point of the window (PeaksModel::kSeedSteps = the
                 // points of a lane per window)
                 // (point of the lane within its window: a constant but for `sec` and `t`)
-                const int gp = (int)(t % kTPW) * kLanePtsPerTile + (sec * NIN + it) * P;
+                const int gp = (ws * NIN + it) * P;
                 if ((it * P) % 16 == 0 && gp % kSeedPts == 0) {
                   if ((rm & mask) != 0u) Model::rec_seed(prep, x[0], rm & mask, rs);
                   if constexpr (BGREC) Model::rec_seed_bg(prep, x[0], rs);
@@ -372,7 +389,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
 #pragma unroll
             for (int i = 0; i < P; ++i) {
               double& acc = (i & 1) ? acc1 : acc0;
-              const int64_t gi = gbase + sbase + (it * P + i) * kWave + l;  // index in the dataset
+              const int64_t gi = gbase + wb + (it * P + i) * kWave + l;  // index in the dataset
               (void)gi;
               if constexpr (LIK == MHX_LIK_NORMAL) {
                 // the y array holds y/sigma (host, once): r = y/sigma - m/sigma in one fma
@@ -406,7 +423,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
       };
       auto tile_body = [&](auto mk, auto rk, auto bgc) {
         if constexpr (LIK == MHX_LIK_POISSON || LIK == MHX_LIK_EXPR) {
-          if (gbase + kTilePoints <= f.n)
+          if (gbase + kTPW * kTilePoints <= f.n)
             tile_body_m(mk, rk, BoolC<true>{}, bgc);
           else
             tile_body_m(mk, rk, BoolC<false>{}, bgc);
@@ -471,6 +488,8 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
       } else {
         tile_work(BoolC<false>{});
       }
+    } else if (kTPW > 1 && t + 1 < nt) {
+      mid_hook(t, buf);  // a wave without a running chain still moves its part of the tiles
     }
 #ifndef MHX_NO_TILE_PRIO
     __builtin_amdgcn_s_setprio(0);  // (tile_prio; a short tile may leave its loop at any level)
