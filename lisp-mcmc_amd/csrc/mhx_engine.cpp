@@ -253,17 +253,31 @@ int choose_split(const mhx_engine* e, const Family& fam, bool capable) {
     const int v = atoi(s);
     return v <= 0 ? 0 : (int)std::min<int64_t>(std::max<int64_t>(by_data, 1), v);
   }
-  // measured on config 2's problem (tools/ab notes in DESIGN.md): the batch kernels win once they
-  // put a workgroup on every CU (2048 chains: 9.0e6 against 5.9e6 chain-steps/s); below that,
-  // about 1024 workgroups in the sweep launch are best (1024 chains x2: 5.6e6 against 4.6e6,
-  // 256 chains x4: 4.4e6 against 1.2e6, one chain x24: 6.0e4 against 7.5e3)
+  // measured (tools/debug/split_sweep.sh, round 2; chain-steps/s batch | best split):
+  //   config 2's problem   64 chains 6.6e5 | 2.4e6 (x4)    256: 2.6e6 | 4.5e6 (x4)
+  //                        512: 5.3e6 | 5.4e6 (x2)         1024: 1.05e7 | 5.9e6    2048: 2.1e7 | 6.3e6
+  //   config 3's problem   16: 4.2e3 | 1.5e5 (x24)    256: 6.7e4 | 2.9e5 (x8)    1024: 2.7e5 | 3.1e5
+  // (round 2, with the recurrence in the split sweep as well:  config 3  16: 2.3e5 (x24)
+  //  256: 4.6e5 (x4)    1024: 2.7e5 | 5.4e5 (x4);  config 2 unchanged: its split sweep is bound by
+  //  the L2, every chain reading the dataset for itself)
+  // The batch kernels (peak skipping, LDS tiles shared by 8 chains) win from about 128
+  // workgroups on when a point is cheap; a point that costs 40 instructions and more (a log per
+  // point, a pseudo-Voigt, an expression compiled as written) keeps the whole GPU busy in split
+  // mode until the batch kernels have a workgroup for every CU.  Below that about 1024
+  // workgroups in the sweep launch are best.
+  bool heavy = false;
+  for (int k = 0; k < e->P.K; ++k) {
+    const FnDesc& fd = e->P.fn[k];
+    heavy = heavy || fd.lik == MHX_LIK_POISSON || fd.lik == MHX_LIK_EXPR ||
+            fd.model == MHX_MODEL_PVOIGT2 || fd.model == MHX_MODEL_EXPR;
+  }
   const int64_t batch_groups = (C + W - 1) / W;
-  if (batch_groups >= 256) return 0;
+  if (batch_groups >= (heavy ? 256 : 128)) return 0;
   // two launches cost about 14 us per iteration: the fused batch kernel is quicker than that up
   // to roughly a dozen 1024-point tiles
   if (by_data < 4) return 0;
-  const int64_t slices = std::min<int64_t>(std::max<int64_t>(2, std::min<int64_t>(1024 / C, 24)),
-                                           by_data);
+  const int64_t want = heavy ? std::max<int64_t>(4, 2048 / C) : std::max<int64_t>(2, 1024 / C);
+  const int64_t slices = std::min<int64_t>(std::min<int64_t>(want, 24), by_data);
   return slices >= 2 ? (int)slices : 0;
 }
 

@@ -567,6 +567,53 @@ __device__ __forceinline__ double sweep_direct(const FnDesc& f, const typename M
   return wave_sum(acc0 + acc1);
 }
 
+// ... with the uniform-grid recurrence of the Gaussian peaks (PeaksModel, model_has_rec): the
+// lane's points are 64 grid points apart here as well, so g, r advance as in sweep(); seeded
+// every kSeedSteps points of the lane counted from the slice's start (no windows, no skipping in
+// split mode), every peak of `rmask` by recurrence, the others directly.  Only for steps whose
+// every |t| is inside the table exp's range (Prep::fast).
+template <class Model, int LIK, bool BGREC>
+__device__ __forceinline__ double sweep_direct_rec(const FnDesc& f,
+                                                   const typename Model::Prep& prep, int64_t p0,
+                                                   int64_t p1, unsigned rmask) {
+  const int l = lane_id();
+  double acc0 = 0.0, acc1 = 0.0;
+  constexpr int S = model_seed_steps<Model>::value;
+  constexpr unsigned all = (1u << model_peaks<Model>::value) - 1u;
+  typename model_rec_state<Model>::type rs;
+  for (int64_t bb = p0; bb < p1; bb += (int64_t)S * kWave) {
+#pragma unroll 1
+    for (int j = 0; j < S; j += 2) {
+      const int64_t b = bb + (int64_t)j * kWave;
+      if (b >= p1) break;
+      const int64_t i0 = b + l, i1 = b + kWave + l;
+      const double xs[2] = {f.x[i0], f.x[i1]};
+      const double y0 = f.y[i0], y1 = f.y[i1];
+      double w0 = 0.0, w1 = 0.0;
+      if constexpr (LIK != MHX_LIK_POISSON) { w0 = f.w[i0]; w1 = f.w[i1]; }
+      if (j == 0) {
+        Model::rec_seed(prep, xs[0], rmask, rs);
+        if constexpr (BGREC) Model::rec_seed_bg(prep, xs[0], rs);
+      }
+      double m[2];
+      Model::template eval_mixed<2, BGREC>(prep, xs, all, rmask, rs, m);
+      if constexpr (LIK == MHX_LIK_NORMAL) {
+        const double r0 = __builtin_fma(-m[0], w0, y0), r1 = __builtin_fma(-m[1], w1, y1);
+        acc0 = __builtin_fma(r0, r0, acc0);
+        acc1 = __builtin_fma(r1, r1, acc1);
+      } else {
+        static_assert(LIK == MHX_LIK_NORMAL || LIK == MHX_LIK_POISSON, "likelihoods of the peaks kernels");
+        const lds_cdptr_t tab = lds_logtab();
+        const double t0 = __builtin_fma(y0, tlog(m[0], tab), -m[0]);
+        const double t1 = __builtin_fma(y1, tlog(m[1], tab), -m[1]);
+        acc0 = acc0 + (i0 < f.n ? t0 : 0.0);
+        acc1 = acc1 + (i1 < f.n ? t1 : 0.0);
+      }
+    }
+  }
+  return wave_sum(acc0 + acc1);
+}
+
 // A problem whose K functions all use one compiled model and likelihood
 template <class Model, int LIK>
 struct FixedSpec {
@@ -577,7 +624,18 @@ struct FixedSpec {
                                                        int64_t p1) {
     typename Model::Prep prep = Model::prepare(pf, f);
     if constexpr (model_has_fast<Model>::value) {
-      if (Model::fast_ok(prep)) return sweep_direct<Model, LIK, true>(f, prep, p0, p1);
+      if (Model::fast_ok(prep)) {
+        if constexpr (model_has_rec<Model>::value &&
+                      (LIK == MHX_LIK_NORMAL || LIK == MHX_LIK_POISSON)) {
+          const unsigned rmask = Model::rec_mask(prep);
+          if (rmask != 0u) {
+            if (__builtin_amdgcn_readfirstlane((int)Model::rec_bg(prep)) != 0)
+              return sweep_direct_rec<Model, LIK, true>(f, prep, p0, p1, rmask);
+            return sweep_direct_rec<Model, LIK, false>(f, prep, p0, p1, rmask);
+          }
+        }
+        return sweep_direct<Model, LIK, true>(f, prep, p0, p1);
+      }
     }
     return sweep_direct<Model, LIK, false>(f, prep, p0, p1);
   }

@@ -124,7 +124,7 @@ def test_split_mode_is_chosen_by_batch_and_dataset_size(mhx):
     s_long = pb.two_peak(n=100000, seed=1)
     s_short = pb.two_peak(n=3000, seed=1)
     for spec, chains, want in ((s_long, 1, "split x24"), (s_long, 256, "split x4"),
-                               (s_long, 1024, "split x2"), (s_long, 2048, None),
+                               (s_long, 512, "split x2"), (s_long, 1024, None), (s_long, 2048, None),
                                (s_short, 1, None), (s_short, 64, None)):
         e, name = engine(mhx, spec, chains, None)
         assert (want in name) if want else ("split" not in name), (chains, name)
