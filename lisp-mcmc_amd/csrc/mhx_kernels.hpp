@@ -497,9 +497,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
     MHX_TIM(lds, 4);
     if (!solo) {  // (a resident tile is never overwritten: nothing to wait for)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of tile t+1 has landed
-#ifndef MHX_X_NOBAR  // (timing experiment only: results are wrong without the barrier)
       __syncthreads();                                   // ... and so has everybody else's
-#endif
     }
     MHX_TIM(lds, 5);
   }
