@@ -381,7 +381,7 @@ __device__ __forceinline__ double mexp2_negsq_safe(double t) {
 // v_rcp_f64 + two Newton steps instead of an IEEE division.  < 1 ulp on normal positive x.
 // x <= 0, subnormal, inf or NaN -> NaN: a rate outside (0, inf) is where the reference errors
 // (log of a negative number is complex, log 0 traps), and a NaN log-posterior freezes the chain.
-__device__ __forceinline__ double mlog(double x) {
+__device__ __attribute__((noinline)) double mlog(double x) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
                Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
@@ -463,7 +463,10 @@ __device__ __forceinline__ double tlog(double x, lds_cdptr_t tab, double A3 = kT
 // e^x in pure IEEE operations (fma, add, ldexp), so that the oracle's mirror mode reproduces it
 // bit for bit: k = rint(x log2 e), r = x - k ln2 (hi/lo), degree-13 Taylor in Horner form.
 // < 1 ulp for |x| < 700.  Used by the bounds prior (M:360), off the hot loop.
-__device__ __forceinline__ double dexp(double x) {
+// NOT inlined: as part of the step kernels its thirteen coefficients were materialised once per
+// launch into vector registers that then stayed occupied through every sweep (four of them
+// spilled: the last scratch of the config-2 kernel); it runs only when a proposal violates a bound.
+__device__ __attribute__((noinline)) double dexp(double x) {
   // beyond the range of a double the answer is decided here (inf, 0, NaN for NaN): the
   // reduction below is meaningless there - it once answered -inf for e^(1e25), a bound
   // violated by 1e30, and the oracle's restatement something else again

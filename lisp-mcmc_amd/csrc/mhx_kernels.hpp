@@ -172,7 +172,9 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
   const int w = wave_in_group();
   const int64_t nt = f.n_tiles;
   double acc0 = 0.0, acc1 = 0.0;
-  const double log_a3 = tlog_a3();  // (Poisson) a constant of tlog() pinned in a VGPR
+  // (Poisson) a constant of tlog() pinned in a VGPR - and only there: the pin cannot be optimised
+  // away, and the other kernels have better uses for the register
+  const double log_a3 = LIK == MHX_LIK_POISSON ? tlog_a3() : kTlogA3;
   (void)log_a3;
   // Tile-level peak skipping and the Gaussian recurrence work on WINDOWS of kPadPoints = 2048
   // points - one tile of the 16-wave family, two of the 8-wave family: the mask of peaks is
