@@ -381,6 +381,8 @@ __device__ __forceinline__ double mexp2_negsq_safe(double t) {
 // v_rcp_f64 + two Newton steps instead of an IEEE division.  < 1 ulp on normal positive x.
 // x <= 0, subnormal, inf or NaN -> NaN: a rate outside (0, inf) is where the reference errors
 // (log of a negative number is complex, log 0 traps), and a NaN log-posterior freezes the chain.
+// (out of line like dexp: it only serves rates within 1/16 of 1 and the arguments that end in NaN,
+// and inlined its constants took registers from the Poisson kernel's loops)
 __device__ __attribute__((noinline)) double mlog(double x) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
