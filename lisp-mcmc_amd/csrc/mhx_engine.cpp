@@ -276,7 +276,10 @@ int choose_split(const mhx_engine* e, const Family& fam, bool capable) {
   // two launches cost about 14 us per iteration: the fused batch kernel is quicker than that up
   // to roughly a dozen 1024-point tiles
   if (by_data < 4) return 0;
-  const int64_t want = heavy ? std::max<int64_t>(4, 2048 / C) : std::max<int64_t>(2, 1024 / C);
+  // (cheap points: beyond 8 slices the partial sums and the extra blocks cost more than they
+  // bring once there are 32 chains and more - 64 chains: x16 2.2e6, x8 2.4e6, x4 2.4e6)
+  const int64_t want = heavy ? std::max<int64_t>(4, 2048 / C)
+                             : std::max<int64_t>(2, std::min<int64_t>(1024 / C, C < 32 ? 24 : 8));
   const int64_t slices = std::min<int64_t>(std::min<int64_t>(want, 24), by_data);
   return slices >= 2 ? (int)slices : 0;
 }
