@@ -77,3 +77,25 @@ def test_mirror_walker_tracks_faithful_walker(orc):
     assert a.age == b.age
     assert np.array_equal(a.last()[0], b.last()[0])          # same accept decisions throughout
     assert abs(a.last()[1] - b.last()[1]) <= REL * op.abs_terms(a.last()[0])
+
+
+def test_bounds_prior_far_outside_the_box(orc):
+    """(exp x) of M:360 beyond the range of a double: the reference signals floating-point-overflow,
+    the faithful mode and the kernel's restatement both answer -inf (which freezes the chain),
+    whatever the size of the violation - a reduction left to itself answered +inf for a bound
+    violated by 1e30 on the device and something finite in the restatement"""
+    s = pb.two_peak(n=300, seed=5)
+    op = s.oracle(orc)
+    for k, v in ((2, 1e30), (2, 1e25), (0, -1e300), (4, 7.2e7), (7, 1e9)):
+        t = s.theta_star.copy()
+        t[k] = v
+        with np.errstate(all="ignore"):
+            a, pa = op.logpost(t, parts=True)
+            b, pm = op.logpost_mirror(t, parts=True)
+        assert pa[1] == -np.inf and pm[1] == -np.inf, (k, v, pa[1], pm[1])
+    # ... and continuous up to there: just inside the range both are finite and agree
+    t = s.theta_star.copy()
+    t[2] = 1.5 + 6.5e7          # exp(650) = 1e282, times 1e10 still a double
+    a, pa = op.logpost(t, parts=True)
+    b, pm = op.logpost_mirror(t, parts=True)
+    assert np.isfinite(pa[1]) and np.isfinite(pm[1]) and abs(pa[1] / pm[1] - 1.0) < 1e-12
