@@ -153,6 +153,26 @@ def test_guarded_form_only_in_the_windows_that_need_it(mhx, orc):
     e2.close()
 
 
+def test_bounds_prior_far_outside_the_box(mhx, orc):
+    """(exp x) of M:360 beyond the range of a double is -inf on the device, in the restatement and
+    in the reference's own arithmetic (where SBCL would signal floating-point-overflow)"""
+    s = pb.two_peak(n=700, seed=5)
+    op = s.oracle(orc)
+    th = np.tile(s.theta_star, (6, 1))
+    th[0, 2], th[1, 2], th[2, 0], th[3, 4], th[4, 7] = 1e30, 1e25, -1e300, 7.2e7, 1e9
+    th[5, 2] = 1.5 + 6.5e7     # exp(650): still inside
+    e = s.engine(mhx, 1)
+    with np.errstate(all="ignore"):
+        got, parts = e.logpost(th, parts=True)
+    for i, t in enumerate(th):
+        with np.errstate(all="ignore"):
+            ref, rp = op.logpost_mirror(t, parts=True)
+            fa, fp = op.logpost(t, parts=True)
+        assert parts[i, 1] == rp[1], (i, parts[i, 1], rp[1])
+        assert (parts[i, 1] == -np.inf) == (i < 5) and (fp[1] == -np.inf) == (i < 5)
+    e.close()
+
+
 @pytest.mark.parametrize("n", [1, 64, 1025, 3000, 40000])
 @pytest.mark.parametrize("logfact_double", [False, True])
 def test_poisson_logpost_equals_mirror(mhx, orc, n, logfact_double):
