@@ -38,6 +38,12 @@ def synth_workload(name, rng_key=0x5EED0001):
     """Synthetic inputs of BASELINE.json's configs."""
     import problems as pb
     rng = np.random.Generator(np.random.Philox(key=rng_key))
+    if name == "c5":
+        # BASELINE config 5's share of one GPU: config 2's problem, 524288 / 8 chains, pooled
+        # adaptive covariance (main() switches the adaptation mode)
+        s, _, b_pt, _ = synth_workload("c2", rng_key)
+        return s, 65536, b_pt, ("65536 chains (config 5's share of one of 8 GPUs) x config 2's problem, "
+                                "pooled adaptive covariance")
     if name in ("c2", "poly7"):
         n = 100000
         x = np.linspace(0.0, 1.0, n)
@@ -189,7 +195,7 @@ def main():
     if args.chains:
         chains = args.chains
     n_adapt = 30000  # (walker-adaptive-steps w) default n, mcmc-fitting.lisp:946
-    pooled = args.adapt == "pooled" or (args.adapt == "auto" and world > 1)
+    pooled = args.adapt == "pooled" or (args.adapt == "auto" and (world > 1 or args.workload == "c5"))
     e = spec.engine(mhx, chains, device=local_rank if world > 1 else 0, seed=0x5EED0003,
                     chain_offset=rank * chains,
                     adapt_mode=mhx.capi.ADAPT_POOLED if pooled else mhx.capi.ADAPT_FAITHFUL)
