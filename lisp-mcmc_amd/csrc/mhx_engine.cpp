@@ -194,6 +194,9 @@ struct mhx_engine {
   // (mhx_comm_init_rank: one process per GPU) or its group's (mhx_group_create)
   nccl_comm_t comm = nullptr;
   bool comm_owned = false;
+  // slot -> chain map of the stepping kernel (ChainState::slot_chain): rebuilt from the chain
+  // states whenever a quarter of the slots in use have finished (compact_slots)
+  DevBuf<int32_t> slot_map;
   bool launch_open = false;  // steps enqueued by launch_steps_enqueue(), not yet finished
   int64_t launch_iters = 0;
 
@@ -539,6 +542,8 @@ int alloc_state(mhx_engine* e) {
   const int Rcap = pow2_ceil(want);
   auto& S = e->S;
   S.n_chains = C;
+  S.slot_chain = nullptr;
+  S.n_slots = (int64_t)C;
   S.chain_offset = e->cfg.chain_offset;
   S.d = d;
   S.R = Rcap;
@@ -622,13 +627,56 @@ int ensure_stage(mhx_engine* e, size_t bytes) {
 }
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// Chains that have finished give up their wave slots - where that pays.  In a long run of many
+// chains the walks end at very different loop indices (:prob-settle), and a workgroup whose
+// chains are mostly done carries idle waves through every tile of every sweep until its last
+// chain ends.  But a wave that has its SIMD to itself runs at 39 % of the SIMD's issue rate where
+// four sharing it get 25 % each, so as long as there is a CU for every workgroup the survivors
+// are better left spread out (measured: packing 4096 chains' survivors made complete runs of
+// config 2 8 % and of poly7 20 % SLOWER).  So: only launches with more workgroups than the GPU
+// holds at once are repacked, and never into fewer workgroups than that - the chains still
+// walking are dealt round-robin over max(what they need, what the GPU holds) workgroups, empty
+// slots marked -1.  The chains' results do not depend on the slot they walk in (per-walker
+// adaptation; Philox is keyed by the chain's global id).  Batch kernels only (split mode has no
+// idle waves; the pooled statistics kernels index chains directly).  MHX_NO_COMPACT=1: off.
+int compact_slots(mhx_engine* e, const std::vector<int32_t>& st, int64_t running) {
+  const char* nc = getenv("MHX_NO_COMPACT");
+  if ((nc && atoi(nc) != 0) || e->split_slices > 0 || e->cfg.adapt_mode == MHX_ADAPT_POOLED || !e->fam)
+    return MHX_OK;
+  const int64_t W = e->fam->waves_per_group;
+  const int64_t in_use = e->S.slot_chain ? e->S.n_slots : e->cfg.n_chains;
+  const int64_t groups = (in_use + W - 1) / W;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus <= 0)
+    cus = 256;
+  const int64_t resident = (int64_t)cus * (W <= 8 ? 2 : 1);  // workgroups the GPU holds at once
+  const char* force = getenv("MHX_COMPACT_ALWAYS");          // (tests: repack small launches too)
+  const int64_t floor_groups = (force && atoi(force) != 0) ? 1 : resident;
+  if (running <= 0 || groups <= floor_groups) return MHX_OK;
+  const int64_t target = std::max<int64_t>((running + W - 1) / W, floor_groups);
+  if (target * 4 > groups * 3) return MHX_OK;  // (worth a copy only when a quarter goes away)
+  std::vector<int32_t> map((size_t)(target * W), -1);
+  int64_t j = 0;
+  for (size_t c = 0; c < st.size(); ++c)
+    if (st[c] == MHX_CHAIN_RUNNING) {
+      map[(size_t)((j % target) * W + j / target)] = (int32_t)c;
+      ++j;
+    }
+  if (!e->slot_map.p && e->slot_map.alloc((size_t)e->cfg.n_chains + (size_t)W) != hipSuccess)
+    return fail(MHX_ENOMEM, "hipMalloc of the slot map failed");
+  HIP_TRY(hipMemcpy(e->slot_map.p, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  e->S.slot_chain = e->slot_map.p;
+  e->S.n_slots = (int64_t)map.size();
+  return MHX_OK;
+}
+
 int count_running(mhx_engine* e, int64_t* n_running) {
   std::vector<int32_t> st((size_t)e->cfg.n_chains);
   HIP_TRY(hipMemcpy(st.data(), e->status.p, st.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
   int64_t r = 0;
   for (int32_t s : st) r += s == MHX_CHAIN_RUNNING;
   *n_running = r;
-  return MHX_OK;
+  return compact_slots(e, st, r);
 }
 
 // The temperature schedule of M:878, entries [lo, hi): (max 1 (* (cos (* x pi (+ 1 (* 2 (floor
@@ -1226,6 +1274,8 @@ int mhx_adaptive_begin(mhx_engine* e, const mhx_run_opts* o) {
   if (rc != MHX_OK) return rc;
   if ((rc = finalize_problem(e)) != MHX_OK) return rc;
   drop_split_graph(e);  // the run description is an argument frozen into the captured launches
+  e->S.slot_chain = nullptr;  // every chain walks again: slot s is chain s (compact_slots)
+  e->S.n_slots = e->cfg.n_chains;
   const int d = e->P.d;
   RunDesc& R = e->R;
   R.n = o->n;                                       // (floor n) M:866
@@ -1344,6 +1394,8 @@ static int plain_steps(mhx_engine* e, int64_t n, const double* L, int per_chain_
   if (rc != MHX_OK) return rc;
   if ((rc = finalize_problem(e)) != MHX_OK) return rc;
   drop_split_graph(e);
+  e->S.slot_chain = nullptr;
+  e->S.n_slots = e->cfg.n_chains;
   const size_t C = (size_t)e->cfg.n_chains, dd = (size_t)e->P.d * e->P.d;
   if (per_chain_l) {
     HIP_TRY(hipMemcpy(e->L.p, L, C * dd * sizeof(double), hipMemcpyHostToDevice));

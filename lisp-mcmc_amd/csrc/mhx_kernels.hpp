@@ -1323,8 +1323,13 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
   lds_begin(lds);
   const ProblemDesc& P = *Pp;
   const int w = wave_in_group(), l = lane_id(), d = P.d;
-  const int64_t c = (int64_t)blockIdx.x * kWavesPerGroup + w;
-  const bool valid = c < S.n_chains;
+  // wave slot -> chain (ChainState::slot_chain: the chains still walking, packed)
+  const int64_t slot = (int64_t)blockIdx.x * kWavesPerGroup + w;
+  const bool in_range = slot < (S.slot_chain ? S.n_slots : S.n_chains);
+  const int64_t mapped =
+      in_range && S.slot_chain ? (int64_t)__builtin_amdgcn_readfirstlane(S.slot_chain[slot]) : slot;
+  const bool valid = in_range && mapped >= 0;  // (-1: an empty slot of the map)
+  const int64_t c = valid ? mapped : 0;
   ChainRegs r;
   r.status = MHX_CHAIN_DONE;
   if (valid) chain_load(S, c, d, r);

@@ -604,7 +604,8 @@ hipError_t rtc_launch_adaptive(const UserProgram& p, hipStream_t st, const Probl
   ChainState s = S;
   RunDesc r = R;
   void* args[] = {(void*)&P, (void*)&s, (void*)&r, (void*)&max_iters, (void*)&plain};
-  return hipModuleLaunchKernel(p.f_adaptive, grid_for(p, S.n_chains), 1, 1, (unsigned)p.fam->threads, 1, 1,
+  return hipModuleLaunchKernel(p.f_adaptive, grid_for(p, S.slot_chain ? S.n_slots : S.n_chains), 1, 1,
+                               (unsigned)p.fam->threads, 1, 1,
                                (unsigned)p.fam->lds_bytes, st, args, nullptr);
 }
 

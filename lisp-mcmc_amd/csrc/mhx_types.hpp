@@ -103,6 +103,11 @@ struct ChainState {
   int32_t* split_pending;  // [C] 1: split_prop / split_u hold a proposal to be judged
   double* split_part;      // [C][K][split_slots]
   int32_t split_slots;
+  // the stepping kernel's wave slots -> chains (batch mode, per-walker adaptation): chains that
+  // have finished give their slots up (mhx_engine.cpp, compact_slots): entry -1 = empty slot.
+  // nullptr: slot s is chain s
+  const int32_t* slot_chain;
+  int64_t n_slots;  // entries of slot_chain
   int32_t split_pad_;
 };
 

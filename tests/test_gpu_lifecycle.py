@@ -70,3 +70,47 @@ def test_create_destroy_does_not_leak_device_memory(mhx):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 32 << 20, (free0, free1)   # each engine holds ~170 MB while alive
+
+
+def test_finished_chains_give_up_their_slots_without_changing_anything(mhx):
+    """Complete walker-adaptive-steps runs of 200 chains end at different loop indices; launches
+    with more workgroups than the GPU holds at once are repacked between launches with the chains
+    still walking (compact_slots; MHX_COMPACT_ALWAYS=1 makes it happen for this small one too).
+    A chain's walk must not depend on it: the same run with MHX_NO_COMPACT=1."""
+    import os
+    os.environ["MHX_COMPACT_ALWAYS"] = "1"
+    s = pb.two_peak(n=1200, seed=3)
+    th0 = pb.perturbed(s.theta_star, 200, 0.01, seed=4)
+    out = []
+    for flag in ("1", None):
+        if flag:
+            os.environ["MHX_NO_COMPACT"] = flag
+        try:
+            e = s.engine(mhx, 200, seed=21)
+            e.init_chains(th0)
+            e.adaptive_begin(6000, 10.0, 1)
+            left = 1
+            while left:
+                left = e.adaptive_advance(250)   # many launches: many chances to repack
+            st = e.state()
+            out.append((st, e.lmatrix(), e.chain_status()[0], e.acceptance(1000)))
+            e.close()
+        finally:
+            os.environ.pop("MHX_NO_COMPACT", None)
+    (a, la, sa, aa), (b, lb, sb, ab) = out
+    os.environ.pop("MHX_COMPACT_ALWAYS", None)
+    assert len(set(a["age"].tolist())) >= 2           # the walks really end at different times
+    for k in ("theta", "logpost", "best_theta", "best_logpost", "age", "length"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(la, lb) and np.array_equal(sa, sb) and np.array_equal(aa, ab)
+    # a second run on the same engine starts from the identity map again
+    os.environ["MHX_COMPACT_ALWAYS"] = "1"
+    e = s.engine(mhx, 40, seed=22)
+    e.init_chains(th0[:40])
+    for _ in range(2):
+        e.adaptive_begin(3000, 10.0, 1)
+        while e.adaptive_advance(500):
+            pass
+        assert (e.chain_status()[0] == mhx.capi.CHAIN_DONE).all()
+    e.close()
+    os.environ.pop("MHX_COMPACT_ALWAYS", None)

@@ -14,8 +14,12 @@ import bench  # noqa: E402
 import lisp_mcmc_amd as mhx  # noqa: E402
 
 ok = True
-for name, chains, small_l in (("c2", 1024, False), ("c3", 256, True), ("c4", 512, False),
-                              ("g23", 512, False), ("poly7", 1024, False)):
+# SOAK_BIG=1: the batch kernels of the 16-wave family instead (4096 chains each)
+BIG = os.environ.get("SOAK_BIG") == "1"
+for name, chains, small_l in ((("c2", 4096, False), ("c3", 4096, True), ("c4", 4096, False),
+                               ("g23", 4096, False), ("poly7", 4096, False)) if BIG else
+                              (("c2", 1024, False), ("c3", 256, True), ("c4", 512, False),
+                               ("g23", 512, False), ("poly7", 1024, False))):
     spec, _, _, desc = bench.synth_workload(name)
     rng = np.random.Generator(np.random.Philox(key=123))
     th0 = spec.theta_star[None, :] * (1.0 + 0.01 * rng.standard_normal((chains, spec.d)))
