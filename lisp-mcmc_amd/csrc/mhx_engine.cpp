@@ -197,6 +197,7 @@ struct mhx_engine {
   // slot -> chain map of the stepping kernel (ChainState::slot_chain): rebuilt from the chain
   // states whenever a quarter of the slots in use have finished (compact_slots)
   DevBuf<int32_t> slot_map;
+  int64_t slots_mapped = 0;  // chains dealt at the last compact_slots (0: identity map)
   bool launch_open = false;  // steps enqueued by launch_steps_enqueue(), not yet finished
   int64_t launch_iters = 0;
 
@@ -633,10 +634,10 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // chain ends.  But a wave that has its SIMD to itself runs at 39 % of the SIMD's issue rate where
 // four sharing it get 25 % each, so as long as there is a CU for every workgroup the survivors
 // are better left spread out (measured: packing 4096 chains' survivors made complete runs of
-// config 2 8 % and of poly7 20 % SLOWER).  So: only launches with more workgroups than the GPU
-// holds at once are repacked, and never into fewer workgroups than that - the chains still
-// walking are dealt round-robin over max(what they need, what the GPU holds) workgroups, empty
-// slots marked -1.  The chains' results do not depend on the slot they walk in (per-walker
+// config 2 8 % and of poly7 20 % SLOWER; dealing them evenly over the same 256 workgroups made
+// them 20 % and 11 % faster).  So: the chains still walking are dealt round-robin over
+// max(what they need, min(what the launch had, what the GPU holds)) workgroups, empty slots
+// marked -1: every CU and SIMD gets its share of the waves that are left.  The chains' results do not depend on the slot they walk in (per-walker
 // adaptation; Philox is keyed by the chain's global id).  Batch kernels only (split mode has no
 // idle waves; the pooled statistics kernels index chains directly).  MHX_NO_COMPACT=1: off.
 int compact_slots(mhx_engine* e, const std::vector<int32_t>& st, int64_t running) {
@@ -652,9 +653,13 @@ int compact_slots(mhx_engine* e, const std::vector<int32_t>& st, int64_t running
   const int64_t resident = (int64_t)cus * (W <= 8 ? 2 : 1);  // workgroups the GPU holds at once
   const char* force = getenv("MHX_COMPACT_ALWAYS");          // (tests: repack small launches too)
   const int64_t floor_groups = (force && atoi(force) != 0) ? 1 : resident;
-  if (running <= 0 || groups <= floor_groups) return MHX_OK;
-  const int64_t target = std::max<int64_t>((running + W - 1) / W, floor_groups);
-  if (target * 4 > groups * 3) return MHX_OK;  // (worth a copy only when a quarter goes away)
+  // chains mapped at the last deal (all of them before the first): a new deal when a quarter of
+  // them has finished since.  With no more workgroups than the GPU holds their number stays, and
+  // the deal only evens out how many waves each CU and SIMD still has to run.
+  const int64_t mapped = e->slots_mapped > 0 ? e->slots_mapped : e->cfg.n_chains;
+  if (running <= 0 || running * 4 > mapped * 3) return MHX_OK;
+  const int64_t target =
+      std::max<int64_t>((running + W - 1) / W, std::min<int64_t>(groups, floor_groups));
   std::vector<int32_t> map((size_t)(target * W), -1);
   int64_t j = 0;
   for (size_t c = 0; c < st.size(); ++c)
@@ -667,6 +672,7 @@ int compact_slots(mhx_engine* e, const std::vector<int32_t>& st, int64_t running
   HIP_TRY(hipMemcpy(e->slot_map.p, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   e->S.slot_chain = e->slot_map.p;
   e->S.n_slots = (int64_t)map.size();
+  e->slots_mapped = running;
   return MHX_OK;
 }
 
@@ -1276,6 +1282,7 @@ int mhx_adaptive_begin(mhx_engine* e, const mhx_run_opts* o) {
   drop_split_graph(e);  // the run description is an argument frozen into the captured launches
   e->S.slot_chain = nullptr;  // every chain walks again: slot s is chain s (compact_slots)
   e->S.n_slots = e->cfg.n_chains;
+  e->slots_mapped = 0;
   const int d = e->P.d;
   RunDesc& R = e->R;
   R.n = o->n;                                       // (floor n) M:866
@@ -1396,6 +1403,7 @@ static int plain_steps(mhx_engine* e, int64_t n, const double* L, int per_chain_
   drop_split_graph(e);
   e->S.slot_chain = nullptr;
   e->S.n_slots = e->cfg.n_chains;
+  e->slots_mapped = 0;
   const size_t C = (size_t)e->cfg.n_chains, dd = (size_t)e->P.d * e->P.d;
   if (per_chain_l) {
     HIP_TRY(hipMemcpy(e->L.p, L, C * dd * sizeof(double), hipMemcpyHostToDevice));
