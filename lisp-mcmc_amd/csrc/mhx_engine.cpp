@@ -667,12 +667,38 @@ int compact_slots(mhx_engine* e, const std::vector<int32_t>& st, int64_t running
       map[(size_t)((j % target) * W + j / target)] = (int32_t)c;
       ++j;
     }
-  if (!e->slot_map.p && e->slot_map.alloc((size_t)e->cfg.n_chains + (size_t)W) != hipSuccess)
+  if (!e->slot_map.p &&
+      e->slot_map.alloc((size_t)(cus * 2 * W) + (size_t)e->cfg.n_chains + (size_t)W) != hipSuccess)
     return fail(MHX_ENOMEM, "hipMalloc of the slot map failed");
   HIP_TRY(hipMemcpy(e->slot_map.p, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   e->S.slot_chain = e->slot_map.p;
   e->S.n_slots = (int64_t)map.size();
   e->slots_mapped = running;
+  return MHX_OK;
+}
+
+// ... and the same at the start of a run whose chains do not fill the GPU: 1024 chains are 128
+// workgroups of 8 - two waves on every SIMD of half the CUs, the other half idle; dealt over 256
+// workgroups of 4 every wave has a SIMD to itself.
+int deal_initial(mhx_engine* e) {
+  const char* nc = getenv("MHX_NO_COMPACT");
+  if ((nc && atoi(nc) != 0) || e->split_slices > 0 || e->cfg.adapt_mode == MHX_ADAPT_POOLED || !e->fam)
+    return MHX_OK;
+  const int64_t W = e->fam->waves_per_group, C = e->cfg.n_chains;
+  const int64_t groups = (C + W - 1) / W;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus <= 0)
+    cus = 256;
+  const int64_t target = std::min<int64_t>(cus, std::max<int64_t>(groups, (C + 3) / 4));
+  if (groups >= cus || target <= groups || C <= W) return MHX_OK;
+  std::vector<int32_t> map((size_t)(target * W), -1);
+  for (int64_t c = 0; c < C; ++c) map[(size_t)((c % target) * W + c / target)] = (int32_t)c;
+  if (!e->slot_map.p && e->slot_map.alloc((size_t)(cus * 2 * W) + (size_t)C + (size_t)W) != hipSuccess)
+    return fail(MHX_ENOMEM, "hipMalloc of the slot map failed");
+  HIP_TRY(hipMemcpy(e->slot_map.p, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  e->S.slot_chain = e->slot_map.p;
+  e->S.n_slots = (int64_t)map.size();
+  e->slots_mapped = C;
   return MHX_OK;
 }
 
@@ -1283,6 +1309,7 @@ int mhx_adaptive_begin(mhx_engine* e, const mhx_run_opts* o) {
   e->S.slot_chain = nullptr;  // every chain walks again: slot s is chain s (compact_slots)
   e->S.n_slots = e->cfg.n_chains;
   e->slots_mapped = 0;
+  if ((rc = deal_initial(e)) != MHX_OK) return rc;
   const int d = e->P.d;
   RunDesc& R = e->R;
   R.n = o->n;                                       // (floor n) M:866
