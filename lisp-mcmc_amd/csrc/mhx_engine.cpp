@@ -689,8 +689,12 @@ int deal_initial(mhx_engine* e) {
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus <= 0)
     cus = 256;
-  const int64_t target = std::min<int64_t>(cus, std::max<int64_t>(groups, (C + 3) / 4));
-  if (groups >= cus || target <= groups || C <= W) return MHX_OK;
+  // up to one workgroup per CU: workgroups of 4; between one and two per CU (8-wave family):
+  // two on EVERY CU instead of two on some and one on the others
+  const int64_t resident = (int64_t)cus * (W <= 8 ? 2 : 1);
+  const int64_t target = groups <= cus ? std::min<int64_t>(cus, std::max<int64_t>(groups, (C + 3) / 4))
+                                       : (groups < resident ? resident : groups);
+  if (target <= groups || C <= W) return MHX_OK;
   std::vector<int32_t> map((size_t)(target * W), -1);
   for (int64_t c = 0; c < C; ++c) map[(size_t)((c % target) * W + c / target)] = (int32_t)c;
   if (!e->slot_map.p && e->slot_map.alloc((size_t)(cus * 2 * W) + (size_t)C + (size_t)W) != hipSuccess)
