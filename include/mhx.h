@@ -232,7 +232,10 @@ void mhx_run_opts_default(mhx_run_opts* o);
 /* Everything before the do loop: schedule, steps-to-settle, initial L (M:866-901). */
 int mhx_adaptive_begin(mhx_engine* e, const mhx_run_opts* o);
 /* Run up to max_iters iterations of the do loop (M:902-942) for every chain that is
- * still running; *n_running (optional) receives how many chains have not finished. */
+ * still running; *n_running (optional) receives how many chains have not finished.
+ * (Asking for n_running lets the engine look at the chain states: between launches it deals
+ * the chains still walking evenly over the GPU's workgroups - a chain's results do not depend
+ * on where it runs; MHX_NO_COMPACT=1 keeps every chain in its first place.) */
 int mhx_adaptive_advance(mhx_engine* e, int64_t max_iters, int64_t* n_running);
 /* begin + advance until every chain is done or mhx_request_stop was called. */
 int mhx_adaptive_steps_full(mhx_engine* e, const mhx_run_opts* o);
