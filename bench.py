@@ -6,12 +6,18 @@ chain of the batch: propose, evaluate the full log-posterior over all data point
 reject, history push, controller bookkeeping (incl. the 200-step proposal adaptation when it
 falls inside the timed region).  Inputs are resident in HBM before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|poly7|c1|c2expr|g23]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|poly7|c1|c2expr|g23]
 
-N > 1: launched by torch.distributed.run, one rank per GPU; chains are sharded by contiguous
-global id ranges (weak scaling: --chains per GPU), no data-path collective in the reference's
-per-walker adaptation mode; the pooled-covariance mode (default for N > 1) adds ONE RCCL
-all-reduce of 1+d+d^2 doubles per 200 iterations, issued by libmhx itself on the engine's stream.
+N > 1 runs either way, chains sharded by contiguous global id ranges (weak scaling: --chains per
+GPU), datasets replicated, no data-path collective in the reference's per-walker adaptation mode;
+the pooled-covariance mode (default for N > 1) adds ONE RCCL all-reduce of 1+d+d^2 doubles per 200
+iterations, issued by libmhx itself on the engines' streams:
+  * `python bench.py --gpus N` by itself: ONE host process drives the N GPUs through mhx_group_*
+    (ncclCommInitAll, the tick's all-reduces inside ncclGroupStart/End) - the reference's own host
+    model, a list of walkers mapped in one image (mcmc-fitting.lisp:1029-1033);
+  * under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: one rank per
+    GPU, each with its engine in a communicator of libmhx's own (mhx_comm_init_rank); torch carries
+    the 128-byte id and the timing barriers.
 """
 import argparse
 import json
@@ -31,7 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # 157.3 TFLOP/s fp32 vector peak)
 N_SIMD, CLOCK_HZ, CYCLES_PER_F64_INSTR = 1024, 2.4e9, 4
 FP64_VALU_PEAK_TFLOPS = N_SIMD * CLOCK_HZ / CYCLES_PER_F64_INSTR * 128 / 1e12
-ROUND_TAG = "r02"  # profiles/<tag>_<workload>_s<steps>_w<warmup>_summary.json
+ROUND_TAG = "r03"  # profiles/<tag>_<workload>_s<steps>_w<warmup>_summary.json
 
 
 def synth_workload(name, rng_key=0x5EED0001):
@@ -158,6 +164,77 @@ def load_profile(workload, steps, warmup):
     return None, None, False
 
 
+def effective_cores():
+    """(threads to use, what they were derived from): the affinity mask says how many CPUs the
+    process may run on, the cgroup's cpu.max how much CPU time it gets - a GPU box hands a
+    one-GPU job a share of a 256-thread host.  MHX_BENCH_CPU_THREADS overrides."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    info = {"affinity": aff, "cgroup_cpu_max": None}
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                info["cgroup_cpu_max"] = " ".join(txt)
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                info["cgroup_cpu_max"] = "%d %d" % (q, per)
+                if q > 0:
+                    quota = q / per
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    n = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    env = os.environ.get("MHX_BENCH_CPU_THREADS")
+    if env:
+        n = max(1, int(env))
+    info["threads"] = n
+    return n, info
+
+
+class Fleet:
+    """the engines of one benchmark process behind one set of calls: an Engine (one GPU) or a
+    Group (mhx_group_*: one host process, several GPUs)"""
+
+    def __init__(self, mhx, spec, chains_per_gpu, devices, pooled, seed, chain_offset=0):
+        self.mhx, self.devices, self.chains = mhx, list(devices), chains_per_gpu * len(devices)
+        mode = mhx.capi.ADAPT_POOLED if pooled else mhx.capi.ADAPT_FAITHFUL
+        if len(self.devices) == 1:
+            self.obj = spec.engine(mhx, chains_per_gpu, device=self.devices[0], seed=seed,
+                                   chain_offset=chain_offset, adapt_mode=mode)
+            self.engines = [self.obj]
+        else:
+            self.obj = mhx.Group(self.chains, spec.d, spec.K, devices=self.devices, seed=seed,
+                                 chain_offset=chain_offset, adapt_mode=mode)
+            spec.apply(self.obj)
+            self.engines = self.obj.engines
+
+    def start(self, th0, n_adapt, l0):
+        self.obj.init_chains(th0)
+        self.obj.adaptive_begin(n_adapt, 10.0, 1, l_matrix=l0)
+
+    def advance(self, iters):
+        self.obj.adaptive_advance(iters, count=False)
+
+    def timing(self, reset=False):
+        return [e.kernel_timing(reset=reset) for e in self.engines]
+
+    def steps(self):
+        return self.obj.counters()[0]
+
+    def trapped(self):
+        return any((e.chain_status()[0] == self.mhx.capi.CHAIN_FP_TRAP).any() for e in self.engines)
+
+    def kernel_name(self):
+        return self.engines[0].kernel_name()
+
+    def close(self):
+        self.obj.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,46 +250,72 @@ def main():
     ap.add_argument("--adapt", default="auto", choices=["auto", "faithful", "pooled"],
                     help="auto: the reference's per-walker rule on 1 GPU, pooled covariance "
                          "(one RCCL all-reduce per 200 iterations) on several")
+    ap.add_argument("--spin-ms", type=float, default=60.0,
+                    help="GPU time spent on a throw-away engine of the same kernel before the walk's "
+                         "warm-up launch, so that the timed launch runs at the clock the chip holds "
+                         "under this load (0: off)")
+    ap.add_argument("--no-direct", action="store_true",
+                    help="skip the second, short measurement with the uniform-grid recurrence off")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(args.gpus, 1):
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    n_gpus = max(args.gpus, 1)
+    # one process per GPU only when a launcher started us that way; `--gpus N` by itself is ONE
+    # process driving N GPUs through mhx_group_*
+    per_rank = world > 1
+    if per_rank and world != n_gpus:
+        raise SystemExit("--gpus %d under a launcher with WORLD_SIZE=%d" % (n_gpus, world))
     import torch
     dist = None
-    if world > 1:
+    if per_rank:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import lisp_mcmc_amd as mhx
 
+    devices = [local_rank] if per_rank else list(range(n_gpus))
+    if not per_rank:
+        have = torch.cuda.device_count()
+        if have < n_gpus:
+            raise SystemExit("--gpus %d but this process sees %d GPU(s)" % (n_gpus, have))
+
     as_expr = args.workload == "c2expr"  # config 2 with the model given as a Lisp closure text
     spec, chains, b_pt, desc = synth_workload("c2" if as_expr else args.workload)
     if args.chains:
         chains = args.chains
     n_adapt = 30000  # (walker-adaptive-steps w) default n, mcmc-fitting.lisp:946
-    pooled = args.adapt == "pooled" or (args.adapt == "auto" and (world > 1 or args.workload == "c5"))
-    e = spec.engine(mhx, chains, device=local_rank if world > 1 else 0, seed=0x5EED0003,
-                    chain_offset=rank * chains,
-                    adapt_mode=mhx.capi.ADAPT_POOLED if pooled else mhx.capi.ADAPT_FAITHFUL)
+    pooled = args.adapt == "pooled" or (args.adapt == "auto" and (n_gpus > 1 or args.workload == "c5"))
+    n_local = chains * len(devices)        # chains this process drives
+    first_id = rank * chains if per_rank else 0
+
+    def make(pooled=pooled):
+        f = Fleet(mhx, spec, chains, devices, pooled, seed=0x5EED0003, chain_offset=first_id)
+        if as_expr:
+            keys, cexpr = mhx.sexpr.lambda_to_expr(
+                "(lambda (x &key b0 b1 a1 mu1 w1 a2 mu2 w2 &allow-other-keys)"
+                " (+ (+ b0 (* b1 x)) (* a1 (exp (- (expt (/ (- x mu1) w1) 2))))"
+                "    (* a2 (exp (- (expt (/ (- x mu2) w2) 2))))))")
+            for e in f.engines:
+                e.set_function_expr(0, cexpr, keys, list(range(8)))
+        return f
+
+    fleet = make()
     if as_expr:
-        keys, cexpr = mhx.sexpr.lambda_to_expr(
-            "(lambda (x &key b0 b1 a1 mu1 w1 a2 mu2 w2 &allow-other-keys)"
-            " (+ (+ b0 (* b1 x)) (* a1 (exp (- (expt (/ (- x mu1) w1) 2))))"
-            "    (* a2 (exp (- (expt (/ (- x mu2) w2) 2))))))")
-        e.set_function_expr(0, cexpr, keys, list(range(8)))
         desc += " [model compiled at run time from its Lisp closure text]"
-    if pooled and dist is not None:
+    collective = None
+    if pooled and n_gpus > 1 and not per_rank:
+        collective = "ncclCommInitAll + ncclAllReduce in ncclGroupStart/End (one host process, mhx_group_*)"
+    if pooled and per_rank:
         # the one exchange step of the path: 1+d+d^2 doubles summed over ranks every 200
         # iterations by libmhx's OWN RCCL communicator (mhx_comm_init_rank): ncclAllReduce on the
         # engine's stream between the statistics kernels and the factorisation, no host
         # synchronisation, no Python in the data path.  torch.distributed only carries the 128-byte
         # communicator id from rank 0 to the others (and the barriers / max of the contract).
-        collective = "libmhx RCCL communicator (ncclAllReduce on the engine's stream)"
+        collective = "libmhx RCCL communicator (mhx_comm_init_rank; ncclAllReduce on the engine's stream)"
+        e = fleet.engines[0]
         # (every rank takes the same branch: rank 0's failure to make an id travels in the
         # broadcast, a failure to join the communicator through an all-reduced flag)
         uid, why = [None], ""
@@ -236,24 +339,26 @@ def main():
             from lisp_mcmc_amd import distributed as mdist
             e.set_allreduce(mdist.torch_allreduce_hook(dist), device_buffer=True)
             collective = "torch.distributed all_reduce hook (libmhx RCCL unavailable: %s)" % (why or "on another rank")
-    # per-chain start: theta* (1 + 0.01 N(0,1)), keyed by GLOBAL chain id
-    rng = np.random.Generator(np.random.Philox(key=0x5EED0002 + rank))
-    th0 = spec.theta_star[None, :] * (1.0 + 0.01 * rng.standard_normal((chains, spec.d)))
-    e.init_chains(th0)
+    # per-chain start: theta* (1 + 0.01 N(0,1)), keyed by GLOBAL chain id (rank r of a launcher
+    # run and device r of a one-process run get the same chains)
+    th0 = np.concatenate([
+        spec.theta_star[None, :] * (1.0 + 0.01 * np.random.Generator(
+            np.random.Philox(key=0x5EED0002 + (first_id // chains) + i)).standard_normal((chains, spec.d)))
+        for i in range(len(devices))])
     # c3: a Poisson rate must stay positive (log-poisson of a negative rate is an error in the
     # reference as well), so the run starts from a small :l-matrix instead of diag(theta) (M:899)
     l0 = np.diag(0.002 * np.abs(spec.theta_star)) if args.workload == "c3" else None
-    e.adaptive_begin(n_adapt, 10.0, 1, l_matrix=l0)
 
     def sync():
-        torch.cuda.synchronize()
+        for dv in devices:
+            torch.cuda.synchronize(dv)
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
     # The warm-up is ONE launch of `warmup` fused iterations and the timed region ONE launch of
-    # `steps` iterations (rocprofv3's kernel trace therefore shows two dispatches of the step
-    # kernel: profiles/ quotes the second).  Only a launch that would run for many seconds is
+    # `steps` iterations per GPU (a pooled run ends its launches on the 200-iteration cadence, so
+    # there it is one launch per tick interval).  Only a launch that would run for many seconds is
     # cut: config 3 at its full 65536 chains x 1e6 points takes 0.14 s per iteration, so launches
     # keep chains x points x iterations under 1e12.
     work = chains * float(sum(len(d[0]) for d in spec.data))
@@ -264,16 +369,36 @@ def main():
             per = max(q for q in range(1, per) if per % q == 0)
         return per, (n // per if per else 0)
 
+    # Clock: a GPU that has idled through the host-side set-up starts its first kernels well under
+    # the clock it holds under load (round 2: GRBM_GUI_ACTIVE / duration = 1.95 GHz in a 3.8 ms
+    # timed launch that followed a 1 ms warm-up, 2.2-2.3 GHz in a 29 ms one).  A throw-away fleet
+    # of the same problem runs the same kernel for --spin-ms first; the walk that is measured -
+    # its warm-up iterations and its timed iterations - is untouched by it.
+    # (a fixed number of iterations, so that the sequence of dispatches is the same in every
+    # profiling pass: about --spin-ms at the rate of the headline workload)
+    spin_ms, n_disp = 0.0, 0  # (n_disp: k_adaptive dispatches per GPU so far - tools/profile_summary.py)
+    fleet.start(th0, n_adapt, l0)
+    if args.spin_ms > 0:
+        spin = make(pooled=False)  # (no communicator of its own: the kernel is the same)
+        spin.start(th0, n_adapt, l0)
+        spin_iters = max(8, min(2000, int(args.spin_ms / 60.0 * 1.6e11 / work)))
+        s_per, s_n = launches_of(spin_iters)
+        for _ in range(s_n):
+            spin.advance(s_per)
+        t = spin.timing(reset=True)
+        spin_ms = max(x["total_ms"] for x in t)
+        n_disp += t[0]["launches"]
+        spin.close()
     w_per, w_n = launches_of(args.warmup) if args.warmup > 0 else (0, 0)
     for _ in range(w_n):
-        e.adaptive_advance(w_per, count=False)
+        fleet.advance(w_per)
+    n_disp += fleet.timing(reset=True)[0]["launches"]
     per_launch, n_launch = launches_of(args.steps)
-    e.kernel_timing(reset=True)
-    steps0 = e.counters()[0]
+    steps0 = fleet.steps()
     sync()
     t0 = time.perf_counter()
     for _ in range(n_launch):
-        e.adaptive_advance(per_launch, count=False)  # one launch = per_launch fused iterations
+        fleet.advance(per_launch)  # one launch (per GPU) = per_launch fused iterations
     sync()
     t1 = time.perf_counter()
     el = t1 - t0
@@ -281,57 +406,69 @@ def main():
         t = torch.tensor([el], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-    kt = e.kernel_timing()
-    chain_steps = e.counters()[0] - steps0
+    kts = fleet.timing()
+    timed_disp = (n_disp, n_disp + kts[0]["launches"])  # [first, past-the-last) of the timed region
+    n_disp += kts[0]["launches"]
+    chain_steps = fleet.steps() - steps0
     if dist is not None:
         t = torch.tensor([float(chain_steps)], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total_steps = float(t.item())
     else:
         total_steps = float(chain_steps)
-    st, _ = e.chain_status()
-    assert (st != mhx.capi.CHAIN_FP_TRAP).all(), "a chain trapped during the benchmark"
-    assert chain_steps == chains * args.steps, (chain_steps, chains, args.steps)
+    assert not fleet.trapped(), "a chain trapped during the benchmark"
+    assert chain_steps == n_local * args.steps, (chain_steps, n_local, args.steps)
 
     n_points = int(sum(len(d[0]) for d in spec.data))
     bytes_step = b_alg(spec, b_pt)
-    kernel_s = kt["total_ms"] * 1e-3  # HIP events on the engine's stream around the launch(es)
+    # HIP events on each engine's own stream around its launch(es); the slowest GPU counts
+    kernel_s = max(k["total_ms"] for k in kts) * 1e-3
+    kt = max(kts, key=lambda k: k["total_ms"])
     alg_gbs = chain_steps * bytes_step / kernel_s / 1e9
+    build_id = mhx.capi.lib().mhx_build_id().decode()
     # The roof that binds is fp64 VALU issue, not HBM: the chains of a workgroup share every data
     # tile through LDS and the dataset sits in L2, so HBM traffic is a fraction of a per cent of
     # the algorithmic bytes.  achieved = VALU wave-instructions per second x 128 (an fma: 2 flop x
     # 64 lanes), with the instructions per data point MEASURED (SQ_INSTS_VALU of the timed launch
     # of this same command, rocprofv3 --pmc, committed under profiles/); peak = 1024 SIMDs x
-    # 2.4 GHz / 4 cycles per wave64 fp64 instruction x 128 = 78.6 TFLOP/s.
-    prof, prof_name, prof_exact = load_profile(args.workload, args.steps, args.warmup) if world == 1 else (None, None, False)
+    # 2.4 GHz / 4 cycles per wave64 fp64 instruction x 128 = 78.6 TFLOP/s (per GPU).
+    prof, prof_name, prof_exact = load_profile(args.workload, args.steps, args.warmup)
     roof = {"bound": "fp64_valu", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": None, "traffic": None,
             "kernel_ms_per_launch": kt["avg_ms"], "launches": kt["launches"],
-            "iterations_per_launch": per_launch,
+            "iterations_per_launch": per_launch if not pooled else None,
+            "timed_dispatches": list(timed_disp),
             "algorithmic_bytes_per_chain_step": bytes_step, "algorithmic_gbs": alg_gbs,
-            "note": "fp64 VALU issue bound: 16 chains share each LDS tile and the dataset is L2 "
-                    "resident, so HBM (hbm_gbs, hbm_frac) does not bind; algorithmic_gbs = the "
+            "note": "per GPU; fp64 VALU issue bound: 16 chains share each LDS tile and the dataset is "
+                    "L2 resident, so HBM (hbm_gbs, hbm_frac) does not bind; algorithmic_gbs = the "
                     "SURVEY 8d bytes per chain-step x chain-steps / kernel time, for reference only"}
+    if n_gpus > 1 and not per_rank:
+        roof["kernel_ms_per_gpu"] = [k["total_ms"] for k in kts]
     if prof is not None:
         try:
             pm, bs = prof["pmc_timed_launch"], prof["bench_stats"]
-            prof_points = (bs["roofline"]["iterations_per_launch"] * bs["config"]["chains_per_gpu"]
-                           * float(bs["config"]["n_points"]))
+            prof_steps = bs["steps"] * bs["config"]["chains_per_gpu"]
+            prof_points = prof_steps * float(bs["config"]["n_points"])
             ipp = pm["SQ_INSTS_VALU"] * 64.0 / prof_points  # wave-instructions x 64 lanes / points
-            instr = ipp * chain_steps * n_points / 64.0     # wave-instructions of THIS timed region
+            steps_gpu = chains * args.steps                  # chain-steps of ONE GPU's timed region
+            instr = ipp * steps_gpu * n_points / 64.0        # its wave-instructions
+            prof_build = (bs.get("build") or {}).get("id")
+            stale = prof_build != build_id
             roof["instr_per_point"] = ipp
-            roof["instr_source"] = ("profiles/%s: SQ_INSTS_VALU of the timed launch%s"
+            roof["instr_source"] = ("profiles/%s: SQ_INSTS_VALU of the timed launch%s%s"
                                     % (prof_name, "" if prof_exact else
                                        " (NOT the same --steps/--warmup: the count per point depends "
-                                       "on where in the walk the launch sits)"))
+                                       "on where in the walk the launch sits)",
+                                       "" if not stale else
+                                       " -- STALE: measured on build %s, this is %s" % (prof_build, build_id)))
+            roof["instr_source_stale"] = stale
             roof["achieved"] = instr * 128.0 / kernel_s / 1e12
             roof["frac"] = roof["achieved"] / FP64_VALU_PEAK_TFLOPS
-            prof_steps = bs["roofline"]["iterations_per_launch"] * bs["config"]["chains_per_gpu"]
             hbm_per_step = (prof["hbm_read_bytes"] + prof["hbm_write_bytes"]) / prof_steps
             # HBM bytes per launch: FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024
             # of the profiled launch, scaled by chain-steps
             roof["traffic"] = hbm_per_step * per_launch * chains
-            roof["hbm_gbs"] = hbm_per_step * chain_steps / kernel_s / 1e9
+            roof["hbm_gbs"] = hbm_per_step * steps_gpu / kernel_s / 1e9
             roof["hbm_frac"] = roof["hbm_gbs"] / HBM_PEAK_GBS
         except Exception:  # a malformed summary must not break the benchmark
             pass
@@ -340,7 +477,7 @@ def main():
                   if args.workload == "c2" else "chain-steps/sec (whole node), workload %s" % args.workload,
         "value": total_steps / el,
         "unit": "chain-steps/s",
-        "n_gpus": world,
+        "n_gpus": n_gpus,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": el / args.steps * 1e3,
@@ -353,24 +490,70 @@ def main():
                    "n_params": spec.d,
                    "adaptation": ("pooled covariance, all-reduce of %d doubles / 200 iterations" % (1 + spec.d + spec.d ** 2))
                    if pooled else "faithful per-walker (no collective)",
-                   "parallelism": "chains sharded over %d GPU(s)" % world,
-                   **({"collective": collective} if (pooled and dist is not None) else {}),
-                   "kernel": "k_adaptive @ " + e.kernel_name()},
+                   "parallelism": ("chains sharded over %d GPU(s), " % n_gpus) +
+                                  ("one process per GPU" if per_rank else "one host process"),
+                   **({"collective": collective} if collective else {}),
+                   "clock_spin": ("%.0f ms of the same kernel on a throw-away engine before the walk's "
+                                  "warm-up launch" % spin_ms) if spin_ms else "none",
+                   "kernel": "k_adaptive @ " + fleet.kernel_name()},
+        "build": {"id": build_id},
         "roofline": roof,
     }
-    if rank == 0 and world == 1 and not args.no_cpu:
-        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # The headline's Gaussians advance by the uniform-grid recurrence (x is a linspace: 3
+    # instructions per point and peak instead of 14).  The same walk on the same data with the
+    # recurrence switched off - what a dataset that is NOT a grid gets - measured the same way
+    # beside it, so that nobody has to guess the factor.
+    if (rank == 0 and not per_rank and n_gpus == 1 and not args.no_direct
+            and args.workload in ("c2", "c5", "c3", "g23")):
+        os.environ["MHX_NO_RECURRENCE"] = "1"  # (read when the dataset is set)
+        try:
+            direct = make()
+        finally:
+            os.environ.pop("MHX_NO_RECURRENCE", None)
+        direct.start(th0, n_adapt, l0)
+        for _ in range(w_n):
+            direct.advance(w_per)
+        n_disp += direct.timing(reset=True)[0]["launches"]
+        d0 = direct.steps()
+        sync()
+        td0 = time.perf_counter()
+        for _ in range(n_launch):
+            direct.advance(per_launch)
+        sync()
+        td = time.perf_counter() - td0
+        dk = direct.timing()[0]
+        out["value_direct_form"] = (direct.steps() - d0) / td
+        out["direct_form"] = {
+            "what": "the same walk and data with the uniform-grid recurrence off (MHX_NO_RECURRENCE=1): "
+                    "every Gaussian by the table-driven exp, as on data whose x is not a grid",
+            "kernel_ms_per_launch": dk["avg_ms"],
+            "dispatches": [n_disp, n_disp + dk["launches"]],
+            "ratio_to_value": out["value"] / out["value_direct_form"]}
+        n_disp += dk["launches"]
+        pmd = (prof or {}).get("pmc_direct_launch")
+        if isinstance(pmd, dict) and "SQ_INSTS_VALU" in pmd and "instr_per_point" in roof:
+            bs = prof["bench_stats"]
+            ippd = pmd["SQ_INSTS_VALU"] * 64.0 / (bs["steps"] * bs["config"]["chains_per_gpu"]
+                                                  * float(bs["config"]["n_points"]))
+            out["direct_form"]["instr_per_point_direct"] = ippd
+            out["direct_form"]["frac"] = (ippd * chains * args.steps * n_points / 64.0 * 128.0
+                                          / (dk["total_ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS)
+        direct.close()
+    if rank == 0 and not per_rank and n_gpus == 1 and not args.no_cpu:
+        ncpu, cinfo = effective_cores()
         one = cpu_baseline(spec, th0, args.cpu_seconds * 0.4, n_adapt, 1, l0)
         allc = cpu_baseline(spec, th0, args.cpu_seconds * 0.6, n_adapt, ncpu, l0) if ncpu > 1 else one
         out["cpu_baseline"] = {
             "value": allc[0], "unit": "chain-steps/s", "cores": ncpu, "kind": "port",
-            "sample": "%d chains (one per core) x %d steps in all of the same workload (%.1f s), "
+            "cores_from": cinfo,
+            "parallel_speedup": allc[0] / one[0] if one[0] else None,
+            "sample": "%d chains (one thread each) x %d steps in all of the same workload (%.1f s), "
                       "oracle/ faithful serial order, glibc libm" % (ncpu, allc[1], allc[2]),
             "single_core": {"value": one[0], "cores": 1,
                             "sample": "1 chain x %d steps (%.1f s)" % (one[1], one[2])}}
     if rank == 0:
         print(json.dumps(out))
-    e.close()
+    fleet.close()
     if dist is not None:
         dist.destroy_process_group()
 

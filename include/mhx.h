@@ -171,6 +171,11 @@ typedef int (*mhx_allreduce_fn)(void* ctx, double* buf, size_t n, int device_buf
 
 /* ---- lifecycle ----------------------------------------------------------- */
 int mhx_version(void);
+/* Which sources this binary was built from: "csrc:<16 hex digits>", the leading digits of the
+ * SHA-256 over the library's sources in a fixed order (csrc/Makefile: SRC_ID).  bench.py and
+ * tools/profile_summary.py store it next to every measurement, so that an instruction count
+ * taken from a committed rocprof summary is only ever combined with the binary that produced it. */
+const char* mhx_build_id(void);
 const char* mhx_last_error(void);
 int mhx_device_count(int* count);
 int mhx_create(const mhx_config* cfg, mhx_engine** out);

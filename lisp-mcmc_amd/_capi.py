@@ -44,6 +44,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, f64p, C.c_size_t, C.c_int)
 # name -> (restype, argtypes): every symbol of include/mhx.h
 SIGNATURES = {
     "mhx_version": (C.c_int, []),
+    "mhx_build_id": (C.c_char_p, []),
     "mhx_last_error": (C.c_char_p, []),
     "mhx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "mhx_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),

@@ -96,22 +96,68 @@ struct Rccl {
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
 };
+// The library is opened RTLD_LOCAL, and that is load-bearing.  Both librccl builds on a ROCm
+// machine (the ROCm installation's and the one PyTorch wheels bundle) export, next to the nccl*
+// entry points, several hundred C++ symbols of global visibility: weak std:: template
+// instantiations and fmt::v7's STB_GNU_UNIQUE data.  Opened RTLD_GLOBAL they join the process's
+// global scope, and every library loaded LATER (hiprtc / comgr for a run-time compiled model, a
+// second HIP user in the same image) binds its own weak copies of those symbols to RCCL's; at
+// exit both sides destroy what each takes to be its own object: `double free or corruption
+// (!prev)` / `free(): invalid pointer` after the work was done (round 2: four full-suite runs
+// with RTLD_GLOBAL [| RTLD_NODELETE] ended that way, none since; DESIGN.md section 6,
+// tests/test_gpu_rccl_stub.py::test_process_with_rccl_and_hiprtc_exits_cleanly).
+// MHX_RCCL_DLOPEN_GLOBAL=1 restores the old flags - for tools/debug/rccl_exit_abort.py only.
+std::string g_rccl_why;  // why rccl().ok is false
 Rccl& rccl() {
   static Rccl r;
   static bool tried = false;
   if (tried) return r;
   tried = true;
-  // the soname first: a host that already has RCCL loaded (PyTorch does) shares that instance
   // MHX_RCCL_LIBRARY: the copy that belongs to the HIP runtime this process uses (the Python
-  // binding points it at PyTorch's bundled librccl.so when it shares PyTorch's libamdhip64)
+  // binding points it at PyTorch's bundled librccl.so when it shares PyTorch's libamdhip64; the
+  // tests point it at their stub); then the soname: a host that already has RCCL loaded shares
+  // that instance
   const char* names[] = {getenv("MHX_RCCL_LIBRARY"), "librccl.so.1", "librccl.so",
                          "/opt/rocm/lib/librccl.so"};
+  const char* dg = getenv("MHX_RCCL_DLOPEN_GLOBAL");
+  const int flags = (dg && atoi(dg) != 0) ? (RTLD_NOW | RTLD_GLOBAL | RTLD_NODELETE)
+                                           : (RTLD_NOW | RTLD_LOCAL);
+  const char* opened = nullptr;
   for (const char* n : names) {
     if (!n || !*n) continue;
-    r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (r.h) break;
+    r.h = dlopen(n, flags);
+    if (r.h) {
+      opened = n;
+      break;
+    }
+    g_rccl_why = dlerror();
   }
-  if (!r.h) return r;
+  if (!r.h) {
+    if (g_rccl_why.empty()) g_rccl_why = "librccl.so not found";
+    return r;
+  }
+  // One HIP runtime per process: the collective is enqueued on OUR stream, so the library must be
+  // bound to the very libamdhip64 libmhx uses.  (A librccl that needs another soname of the
+  // runtime - a different ROCm major - would bring a second runtime into the process: its
+  // hipStream_t handles are not ours.)  Compared by the address both sides resolve a HIP entry
+  // point to.
+  {
+    void* theirs = dlsym(r.h, "hipStreamSynchronize");
+    void* ours = reinterpret_cast<void*>(&hipStreamSynchronize);
+    if (theirs && theirs != ours) {
+      Dl_info a{}, b{};
+      (void)dladdr(theirs, &a);
+      (void)dladdr(ours, &b);
+      char buf[768];
+      snprintf(buf, sizeof buf, "%s is bound to HIP runtime %s, libmhx to %s: refused (one HIP "
+               "runtime per process; set MHX_RCCL_LIBRARY to the librccl of the runtime in use)",
+               opened, a.dli_fname ? a.dli_fname : "?", b.dli_fname ? b.dli_fname : "?");
+      g_rccl_why = buf;
+      dlclose(r.h);
+      r.h = nullptr;
+      return r;
+    }
+  }
 #define SYM(field, name) *(void**)(&r.field) = dlsym(r.h, name)
   SYM(GetUniqueId, "ncclGetUniqueId");
   SYM(CommInitRank, "ncclCommInitRank");
@@ -124,7 +170,11 @@ Rccl& rccl() {
 #undef SYM
   r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllReduce &&
          r.GroupStart && r.GroupEnd;
+  if (!r.ok) g_rccl_why = std::string(opened) + " lacks one of the eight nccl* entry points libmhx binds";
   return r;
+}
+const char* rccl_err(int rc) {
+  return rccl().GetErrorString ? rccl().GetErrorString(rc) : "error";
 }
 constexpr int kNcclDouble = 8, kNcclSum = 0;
 
@@ -218,6 +268,11 @@ void drop_split_graph(mhx_engine* e);
 int use_device(mhx_engine* e) {
   HIP_TRY(hipSetDevice(e->device));
   return MHX_OK;
+}
+
+// wait for whatever an engine has in its queue (error paths: nothing is reported from here)
+void drain(mhx_engine* e) {
+  if (hipSetDevice(e->device) == hipSuccess && e->stream) (void)hipStreamSynchronize(e->stream);
 }
 
 // The C++ type (csrc/mhx_device.hpp) that evaluates function f with everything about its shape
@@ -638,12 +693,12 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // them 20 % and 11 % faster).  So: the chains still walking are dealt round-robin over
 // max(what they need, min(what the launch had, what the GPU holds)) workgroups, empty slots
 // marked -1: every CU and SIMD gets its share of the waves that are left.  The chains' results do not depend on the slot they walk in (per-walker
-// adaptation; Philox is keyed by the chain's global id).  Batch kernels only (split mode has no
-// idle waves; the pooled statistics kernels index chains directly).  MHX_NO_COMPACT=1: off.
+// adaptation; Philox is keyed by the chain's global id; in the pooled mode the statistics kernels
+// index chains, not slots, and the pooled factor is the same for every chain).  Batch kernels
+// only (split mode has no idle waves).  MHX_NO_COMPACT=1: off.
 int compact_slots(mhx_engine* e, const std::vector<int32_t>& st, int64_t running) {
   const char* nc = getenv("MHX_NO_COMPACT");
-  if ((nc && atoi(nc) != 0) || e->split_slices > 0 || e->cfg.adapt_mode == MHX_ADAPT_POOLED || !e->fam)
-    return MHX_OK;
+  if ((nc && atoi(nc) != 0) || e->split_slices > 0 || !e->fam) return MHX_OK;
   const int64_t W = e->fam->waves_per_group;
   const int64_t in_use = e->S.slot_chain ? e->S.n_slots : e->cfg.n_chains;
   const int64_t groups = (in_use + W - 1) / W;
@@ -682,8 +737,7 @@ int compact_slots(mhx_engine* e, const std::vector<int32_t>& st, int64_t running
 // workgroups of 4 every wave has a SIMD to itself.
 int deal_initial(mhx_engine* e) {
   const char* nc = getenv("MHX_NO_COMPACT");
-  if ((nc && atoi(nc) != 0) || e->split_slices > 0 || e->cfg.adapt_mode == MHX_ADAPT_POOLED || !e->fam)
-    return MHX_OK;
+  if ((nc && atoi(nc) != 0) || e->split_slices > 0 || !e->fam) return MHX_OK;
   const int64_t W = e->fam->waves_per_group, C = e->cfg.n_chains;
   const int64_t groups = (C + W - 1) / W;
   int cus = 0;
@@ -740,9 +794,24 @@ int ensure_temps(mhx_engine* e, int64_t lo, int64_t hi) {
     temps[(size_t)(x - lo)] = v > 1.0 ? v : 1.0;
   }
   HIP_TRY(hipStreamSynchronize(e->stream));  // (a launch may still be reading the old window)
-  if ((int64_t)e->temps.n < top - lo && e->temps.alloc(temps.size(), false) != hipSuccess)
-    return fail(MHX_ENOMEM, "hipMalloc(temperature schedule, %zu) failed", temps.size());
-  HIP_TRY(hipMemcpy(e->temps.p, temps.data(), temps.size() * sizeof(double), hipMemcpyHostToDevice));
+  if ((int64_t)e->temps.n < top - lo) {
+    // the new buffer first, the old one released only once it exists: a failed allocation
+    // leaves R.temps and the window it describes as they were
+    DevBuf<double> fresh;
+    if (fresh.alloc(temps.size(), false) != hipSuccess)
+      return fail(MHX_ENOMEM, "hipMalloc(temperature schedule, %zu) failed", temps.size());
+    std::swap(e->temps.p, fresh.p);
+    std::swap(e->temps.n, fresh.n);
+    R.temps = nullptr;  // (the old window went with `fresh`; set again below)
+    e->temps_count = 0;
+  }
+  if (hipMemcpy(e->temps.p, temps.data(), temps.size() * sizeof(double), hipMemcpyHostToDevice) !=
+      hipSuccess) {
+    R.temps = nullptr;
+    e->temps_count = 0;
+    e->run_ready = false;  // no schedule on the device: the run cannot go on
+    return fail(MHX_EDEVICE, "copying the temperature schedule to the device failed");
+  }
   R.temps = e->temps.p;
   R.temps_first = lo;
   e->temps_count = top - lo;
@@ -825,6 +894,10 @@ int launch_steps_enqueue(mhx_engine* e, int64_t iters, int plain) {
   HIP_TRY(hipEventRecord(e->ev1, e->stream));
   e->launch_open = true;
   e->launch_iters = iters;
+  // counted when the launch is in the queue, not when somebody has waited for it: the chains'
+  // loop indices move with the kernel, and the schedule window and the pooled cadence of the
+  // next launch are derived from this count whatever happens on the host in between
+  if (!plain) e->global_iter += iters;
   return MHX_OK;
 }
 int launch_steps_finish(mhx_engine* e) {
@@ -865,8 +938,7 @@ int pool_enqueue_allreduce(mhx_engine* e) {  // inside ncclGroupStart/End when a
   const int rc = rccl().AllReduce(e->pool_vec.p, e->pool_vec.p, E, kNcclDouble, kNcclSum, e->comm,
                                   e->stream);
   if (rc != 0)
-    return fail(MHX_ECOMM, "ncclAllReduce: %s",
-                rccl().GetErrorString ? rccl().GetErrorString(rc) : "error");
+    return fail(MHX_ECOMM, "ncclAllReduce: %s", rccl_err(rc));
   return MHX_OK;
 }
 int pool_enqueue_factor(mhx_engine* e) {
@@ -911,6 +983,10 @@ int pool_refresh(mhx_engine* e) {
 extern "C" {
 
 int mhx_version(void) { return MHX_VERSION; }
+#ifndef MHX_SOURCE_ID
+#define MHX_SOURCE_ID "unknown"
+#endif
+const char* mhx_build_id(void) { return "csrc:" MHX_SOURCE_ID; }
 const char* mhx_last_error(void) { return g_err.c_str(); }
 
 int mhx_device_count(int* count) {
@@ -1217,7 +1293,8 @@ int mhx_set_likelihood_expr(mhx_engine* e, int k, const char* expr) {
   return MHX_OK;
 }
 
-int mhx_init_chains(mhx_engine* e, const double* theta0, int broadcast) {
+// in two halves, so that a group has every device working before it waits for the first
+static int init_chains_enqueue(mhx_engine* e, const double* theta0, int broadcast) {
   if (!e || !theta0) return fail(MHX_EINVAL, "engine/theta0 is NULL");
   int rc = use_device(e);
   if (rc != MHX_OK) return rc;
@@ -1231,12 +1308,22 @@ int mhx_init_chains(mhx_engine* e, const double* theta0, int broadcast) {
   } else {
     HIP_TRY(hipMemcpy(e->theta.p, theta0, (size_t)C * d * sizeof(double), hipMemcpyHostToDevice));
   }
+  e->chains_ready = false;
+  e->run_ready = false;
   HIP_TRY(do_init(e));
+  return MHX_OK;
+}
+static int init_chains_finish(mhx_engine* e) {
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->launches++;
   e->chains_ready = true;
-  e->run_ready = false;
   return MHX_OK;
+}
+int mhx_init_chains(mhx_engine* e, const double* theta0, int broadcast) {
+  const int rc = init_chains_enqueue(e, theta0, broadcast);
+  return rc != MHX_OK ? rc : init_chains_finish(e);
 }
 
 int mhx_logpost(mhx_engine* e, const double* theta, size_t n, double* out, double* parts) {
@@ -1298,7 +1385,7 @@ void mhx_run_opts_default(mhx_run_opts* o) {
   o->auto_mode = 1;      // (auto (or :prob-settle :slope-settle nil)) evaluates to :prob-settle
 }
 
-int mhx_adaptive_begin(mhx_engine* e, const mhx_run_opts* o) {
+static int adaptive_begin_enqueue(mhx_engine* e, const mhx_run_opts* o) {
   if (!e || !o) return fail(MHX_EINVAL, "NULL argument");
   if (!e->chains_ready) return fail(MHX_ESTATE, "mhx_init_chains has not been called");
   if (o->n < 0) return fail(MHX_EINVAL, "n must be >= 0");
@@ -1343,13 +1430,30 @@ int mhx_adaptive_begin(mhx_engine* e, const mhx_run_opts* o) {
       HIP_TRY(hipMemcpy(e->L.p, full.data(), full.size() * sizeof(double), hipMemcpyHostToDevice));
     }
   }
+  e->run_ready = false;
+  HIP_TRY(hipMemsetAsync(e->pool_valid.p, 0, sizeof(int32_t), e->stream));
   HIP_TRY(e->fam->initial_l(e->stream, e->S, R, o->l_matrix ? 1 : 0, o->temperature));
+  return MHX_OK;
+}
+static int adaptive_begin_finish(mhx_engine* e) {
+  int rc = use_device(e);
+  if (rc != MHX_OK) return rc;
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->launches++;
   e->run_ready = true;
   e->global_iter = 0;
-  HIP_TRY(hipMemset(e->pool_valid.p, 0, sizeof(int32_t)));
   return MHX_OK;
+}
+int mhx_adaptive_begin(mhx_engine* e, const mhx_run_opts* o) {
+  const int rc = adaptive_begin_enqueue(e, o);
+  return rc != MHX_OK ? rc : adaptive_begin_finish(e);
+}
+
+// A failure between begin and the end of a run leaves host and device bookkeeping apart (some
+// launches went out, others did not): the run is over, a new mhx_adaptive_begin starts the next.
+static int run_failed(mhx_engine* e, int rc) {
+  e->run_ready = false;
+  return rc;
 }
 
 int mhx_adaptive_advance(mhx_engine* e, int64_t max_iters, int64_t* n_running) {
@@ -1365,10 +1469,9 @@ int mhx_adaptive_advance(mhx_engine* e, int64_t max_iters, int64_t* n_running) {
     while (left > 0) {
       const int64_t to_tick = 200 - (e->global_iter % 200);
       const int64_t now = std::min(left, to_tick);
-      if ((rc = launch_steps(e, now, 0)) != MHX_OK) return rc;
-      e->global_iter += now;
+      if ((rc = launch_steps(e, now, 0)) != MHX_OK) return run_failed(e, rc);
       left -= now;
-      if (e->global_iter % 200 == 0 && (rc = pool_refresh(e)) != MHX_OK) return rc;
+      if (e->global_iter % 200 == 0 && (rc = pool_refresh(e)) != MHX_OK) return run_failed(e, rc);
     }
   } else {
     // (one launch per call unless it would outrun the schedule window: then window by window,
@@ -1376,17 +1479,16 @@ int mhx_adaptive_advance(mhx_engine* e, int64_t max_iters, int64_t* n_running) {
     int64_t left = max_iters;
     while (left > 0) {
       const int64_t now = std::min(left, kTempsWindow);
-      if ((rc = launch_steps(e, now, 0)) != MHX_OK) return rc;
-      e->global_iter += now;
+      if ((rc = launch_steps(e, now, 0)) != MHX_OK) return run_failed(e, rc);
       left -= now;
       if (left > 0) {
         int64_t running = 0;
-        if ((rc = count_running(e, &running)) != MHX_OK) return rc;
+        if ((rc = count_running(e, &running)) != MHX_OK) return run_failed(e, rc);
         if (running == 0) break;
       }
     }
   }
-  if (n_running) return count_running(e, n_running);
+  if (n_running && (rc = count_running(e, n_running)) != MHX_OK) return run_failed(e, rc);
   return MHX_OK;
 }
 
@@ -1749,10 +1851,10 @@ const char* mhx_kernel_name(mhx_engine* e) {
 int mhx_comm_get_unique_id(uint8_t id[128]) {
   if (!id) return fail(MHX_EINVAL, "id is NULL");
   Rccl& r = rccl();
-  if (!r.ok) return fail(MHX_ECOMM, "librccl.so could not be loaded");
+  if (!r.ok) return fail(MHX_ECOMM, "RCCL unavailable: %s", g_rccl_why.c_str());
   nccl_unique_id u;
   const int rc = r.GetUniqueId(&u);
-  if (rc != 0) return fail(MHX_ECOMM, "ncclGetUniqueId: %s", r.GetErrorString ? r.GetErrorString(rc) : "error");
+  if (rc != 0) return fail(MHX_ECOMM, "ncclGetUniqueId: %s", rccl_err(rc));
   memcpy(id, u.internal, 128);
   return MHX_OK;
 }
@@ -1761,7 +1863,7 @@ int mhx_comm_init_rank(mhx_engine* e, const uint8_t id[128], int rank, int n_ran
   if (!e || !id) return fail(MHX_EINVAL, "NULL argument");
   if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(MHX_EINVAL, "rank %d of %d", rank, n_ranks);
   Rccl& r = rccl();
-  if (!r.ok) return fail(MHX_ECOMM, "librccl.so could not be loaded");
+  if (!r.ok) return fail(MHX_ECOMM, "RCCL unavailable: %s", g_rccl_why.c_str());
   int rc = use_device(e);
   if (rc != MHX_OK) return rc;
   if (e->comm && e->comm_owned) (void)r.CommDestroy(e->comm);
@@ -1771,7 +1873,7 @@ int mhx_comm_init_rank(mhx_engine* e, const uint8_t id[128], int rank, int n_ran
   const int nr = r.CommInitRank(&e->comm, n_ranks, u, rank);
   if (nr != 0) {
     e->comm = nullptr;
-    return fail(MHX_ECOMM, "ncclCommInitRank: %s", r.GetErrorString ? r.GetErrorString(nr) : "error");
+    return fail(MHX_ECOMM, "ncclCommInitRank: %s", rccl_err(nr));
   }
   e->comm_owned = true;
   return MHX_OK;
@@ -1837,14 +1939,26 @@ int group_pool_tick(mhx_group* g) {
   }
   if (g->eng.size() > 1) {
     if (g->rccl_comms) {
+      // one collective per device, issued by this one thread: inside ncclGroupStart/End, each
+      // call with ITS device current.  Whatever fails in between, the group is closed again
+      // (an open group would swallow every later nccl call of the process).
       Rccl& r = rccl();
-      if (r.GroupStart() != 0) return fail(MHX_ECOMM, "ncclGroupStart failed");
+      int nr = r.GroupStart();
+      if (nr != 0) return fail(MHX_ECOMM, "ncclGroupStart: %s", rccl_err(nr));
       for (mhx_engine* e : g->eng) {
-        HIP_TRY(hipSetDevice(e->device));
+        if (hipSetDevice(e->device) != hipSuccess) {
+          rc = fail(MHX_EDEVICE, "hipSetDevice(%d) failed inside the collective group", e->device);
+          break;
+        }
         if ((rc = pool_enqueue_allreduce(e)) != MHX_OK) break;
       }
-      if (r.GroupEnd() != 0 && rc == MHX_OK) rc = fail(MHX_ECOMM, "ncclGroupEnd failed");
-      if (rc != MHX_OK) return rc;
+      const std::string keep = g_err;
+      nr = r.GroupEnd();
+      if (rc != MHX_OK) {
+        g_err = keep;  // the first failure is the one reported
+        return rc;
+      }
+      if (nr != 0) return fail(MHX_ECOMM, "ncclGroupEnd: %s", rccl_err(nr));
     } else if ((rc = group_pool_sum_local(g)) != MHX_OK) {
       return rc;
     }
@@ -1854,6 +1968,17 @@ int group_pool_tick(mhx_group* g) {
     if ((rc = pool_enqueue_factor(e)) != MHX_OK) return rc;
   }
   return MHX_OK;
+}
+// (see run_failed: after a failure inside a run no engine of the group may be advanced again)
+int group_run_failed(mhx_group* g, int rc) {
+  const std::string keep = g_err;
+  for (mhx_engine* e : g->eng) {
+    if (e->launch_open) (void)launch_steps_finish(e);
+    drain(e);
+    e->run_ready = false;
+  }
+  g_err = keep;
+  return rc;
 }
 }  // namespace
 
@@ -1891,15 +2016,20 @@ int mhx_group_create(const mhx_config* cfg, const int32_t* devices, int n_device
     g->first.push_back(first);
     g->count.push_back(count);
   }
-  if (n_devices > 1 && cfg->adapt_mode == MHX_ADAPT_POOLED && distinct) {
+  // MHX_GROUP_FORCE_RCCL=1 (tests): engines that share a device take the communicator branch
+  // too - only a stand-in librccl accepts that (tests/stub_rccl); the real one wants one device
+  // per rank, which is why such groups otherwise sum through the host (group_pool_sum_local)
+  const char* fr = getenv("MHX_GROUP_FORCE_RCCL");
+  const bool force_rccl = fr && atoi(fr) != 0;
+  if (n_devices > 1 && cfg->adapt_mode == MHX_ADAPT_POOLED && (distinct || force_rccl)) {
     Rccl& r = rccl();
-    if (!r.ok) return group_fail_cleanup(g, fail(MHX_ECOMM, "librccl.so could not be loaded"));
+    if (!r.ok) return group_fail_cleanup(g, fail(MHX_ECOMM, "RCCL unavailable: %s", g_rccl_why.c_str()));
     std::vector<nccl_comm_t> comms((size_t)n_devices, nullptr);
     std::vector<int> devs(devices, devices + n_devices);
     const int nr = r.CommInitAll(comms.data(), n_devices, devs.data());
     if (nr != 0)
       return group_fail_cleanup(g, fail(MHX_ECOMM, "ncclCommInitAll: %s",
-                                        r.GetErrorString ? r.GetErrorString(nr) : "error"));
+                                        rccl_err(nr)));
     for (int i = 0; i < n_devices; ++i) {
       g->eng[(size_t)i]->comm = comms[(size_t)i];
       g->eng[(size_t)i]->comm_owned = true;
@@ -1971,13 +2101,23 @@ int mhx_group_request_stop(mhx_group* g) { MHX_GROUP_EACH(mhx_request_stop(e)); 
 
 int mhx_group_init_chains(mhx_group* g, const double* theta0, int broadcast) {
   if (!g || !theta0) return fail(MHX_EINVAL, "NULL argument");
+  // the first step of every chain (M:1148-1163) is a full log-posterior: enqueued on every
+  // device before the first is waited for
   for (size_t i = 0; i < g->eng.size(); ++i) {
     mhx_engine* e = g->eng[i];
     const double* th = broadcast ? theta0 : theta0 + (size_t)g->first[i] * (size_t)e->P.d;
-    const int rc = mhx_init_chains(e, th, broadcast);
-    if (rc != MHX_OK) return rc;
+    const int rc = init_chains_enqueue(e, th, broadcast);
+    if (rc != MHX_OK) {  // (what is already in the queues runs out; nobody is marked ready)
+      for (size_t j = 0; j < i; ++j) drain(g->eng[j]);
+      return rc;
+    }
   }
-  return MHX_OK;
+  int rc = MHX_OK;
+  for (mhx_engine* e : g->eng) {
+    const int r = init_chains_finish(e);
+    if (rc == MHX_OK) rc = r;
+  }
+  return rc;
 }
 
 int mhx_group_adaptive_begin(mhx_group* g, const mhx_run_opts* o) {
@@ -1986,11 +2126,21 @@ int mhx_group_adaptive_begin(mhx_group* g, const mhx_run_opts* o) {
     mhx_run_opts oi = *o;
     if (o->l_matrix && o->l_matrix_per_chain)
       oi.l_matrix = o->l_matrix + (size_t)g->first[i] * (size_t)g->eng[i]->P.d * g->eng[i]->P.d;
-    const int rc = mhx_adaptive_begin(g->eng[i], &oi);
-    if (rc != MHX_OK) return rc;
+    const int rc = adaptive_begin_enqueue(g->eng[i], &oi);
+    if (rc != MHX_OK) {
+      for (size_t j = 0; j < i; ++j) drain(g->eng[j]);
+      return rc;
+    }
   }
+  int rc = MHX_OK;
+  for (mhx_engine* e : g->eng) {
+    const int r = adaptive_begin_finish(e);
+    if (rc == MHX_OK) rc = r;
+  }
+  if (rc != MHX_OK)
+    for (mhx_engine* e : g->eng) e->run_ready = false;
   g->global_iter = 0;
-  return MHX_OK;
+  return rc;
 }
 
 int mhx_group_adaptive_advance(mhx_group* g, int64_t max_iters, int64_t* n_running) {
@@ -2000,42 +2150,38 @@ int mhx_group_adaptive_advance(mhx_group* g, int64_t max_iters, int64_t* n_runni
     if (!e->run_ready) return fail(MHX_ESTATE, "mhx_group_adaptive_begin has not been called");
   const bool pooled = g->eng[0]->cfg.adapt_mode == MHX_ADAPT_POOLED;
   int rc = MHX_OK;
+  auto count_all = [&](int64_t* total) -> int {
+    *total = 0;
+    for (mhx_engine* e : g->eng) {
+      int64_t r = 0;
+      int rc2 = use_device(e);
+      if (rc2 == MHX_OK) rc2 = count_running(e, &r);
+      if (rc2 != MHX_OK) return rc2;
+      *total += r;
+    }
+    return MHX_OK;
+  };
   int64_t left = max_iters;
   while (left > 0) {
     const int64_t now = pooled ? std::min<int64_t>(left, 200 - (g->global_iter % 200))
                                : std::min<int64_t>(left, kTempsWindow);
     for (mhx_engine* e : g->eng) {  // every GPU gets its launch before any is waited for
-      if ((rc = use_device(e)) != MHX_OK) return rc;
-      if ((rc = launch_steps_enqueue(e, now, 0)) != MHX_OK) return rc;
+      if ((rc = use_device(e)) != MHX_OK) return group_run_failed(g, rc);
+      if ((rc = launch_steps_enqueue(e, now, 0)) != MHX_OK) return group_run_failed(g, rc);
     }
-    for (mhx_engine* e : g->eng) {
-      if ((rc = launch_steps_finish(e)) != MHX_OK) return rc;
-      e->global_iter += now;
-    }
+    for (mhx_engine* e : g->eng)
+      if ((rc = launch_steps_finish(e)) != MHX_OK) return group_run_failed(g, rc);
     g->global_iter += now;
     left -= now;
-    if (pooled && g->global_iter % 200 == 0 && (rc = group_pool_tick(g)) != MHX_OK) return rc;
+    if (pooled && g->global_iter % 200 == 0 && (rc = group_pool_tick(g)) != MHX_OK)
+      return group_run_failed(g, rc);
     if (left > 0 && (!pooled || g->global_iter % 200 == 0)) {  // "until done": look at the chains
       int64_t total = 0;
-      for (mhx_engine* e : g->eng) {
-        int64_t r = 0;
-        if ((rc = use_device(e)) != MHX_OK) return rc;
-        if ((rc = count_running(e, &r)) != MHX_OK) return rc;
-        total += r;
-      }
+      if ((rc = count_all(&total)) != MHX_OK) return group_run_failed(g, rc);
       if (total == 0) break;
     }
   }
-  if (n_running) {
-    int64_t total = 0;
-    for (mhx_engine* e : g->eng) {
-      int64_t r = 0;
-      if ((rc = use_device(e)) != MHX_OK) return rc;
-      if ((rc = count_running(e, &r)) != MHX_OK) return rc;
-      total += r;
-    }
-    *n_running = total;
-  }
+  if (n_running && (rc = count_all(n_running)) != MHX_OK) return group_run_failed(g, rc);
   return MHX_OK;
 }
 

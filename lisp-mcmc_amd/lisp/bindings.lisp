@@ -49,6 +49,7 @@ library, or without a gfx950 device, walker-create signals MHX-ERROR."
   (l-matrix-per-chain :int32))
 
 (cffi:defcfun ("mhx_version" %mhx-version) :int)
+(cffi:defcfun ("mhx_build_id" %mhx-build-id) :string)
 (cffi:defcfun ("mhx_last_error" %mhx-last-error) :string)
 (cffi:defcfun ("mhx_device_count" %mhx-device-count) :int (count :pointer))
 (cffi:defcfun ("mhx_create" %mhx-create) :int (cfg :pointer) (out :pointer))

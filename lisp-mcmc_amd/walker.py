@@ -356,6 +356,22 @@ def _percentile(n, seq):  # nth-percentile M:1493-1504
     return float((copy[lo] + copy[lo + 1]) / 2)
 
 
+def lplist_covariance(v):
+    """lplist-covariance M:614-643 of N parameter vectors [N, d], in the reference's own order of
+    operations: averages (/ (reduce #'+ x) N) M:626, then per entry the serial sum over the points
+    of (/ (* a_ik a_jk) N) M:636-643 - the division inside the sum.  np.cumsum accumulates strictly
+    left to right (np.sum adds pairwise), so the result has the reference's bits."""
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    n, d = v.shape
+    avg = np.cumsum(v, axis=0)[-1] / n
+    an = v - avg
+    cov = np.empty((d, d))
+    for i in range(d):
+        for j in range(d):
+            cov[i, j] = np.cumsum((an[:, i] * an[:, j]) / n)[-1]
+    return cov
+
+
 def walker_get(walker, get=":steps", take=None, param=None, chain=0):
     """(walker-get walker &key get take param) M:487-543, served from the device trace."""
     e = walker.engine
@@ -386,9 +402,10 @@ def walker_get(walker, get=":steps", take=None, param=None, chain=0):
         return [s.params for s in steps]
     if g == "param":
         return [s.params[_key(param)] for s in steps]
-    if g == "unique-steps":  # M:492-496 (equal on probs)
+    if g == "unique-steps":  # M:492-496: `equal` on two double-floats is eql - the same BITS
+        bits = np.asarray(prob, dtype=np.float64).view(np.uint64)  # (0.0 / -0.0 differ, NaN = NaN)
         return [steps[i].params for i in range(len(steps))
-                if i + 1 >= len(steps) or steps[i].prob != steps[i + 1].prob]
+                if i + 1 >= len(steps) or bits[i] != bits[i + 1]]
     if g == "forward-steps":  # M:497-502
         return [steps[i].params for i in range(len(steps) - 1)
                 if not steps[i].prob <= steps[i + 1].prob]
@@ -399,9 +416,9 @@ def walker_get(walker, get=":steps", take=None, param=None, chain=0):
         return best
     if g == "median-params":  # M:516-523
         return {k: _percentile(50, th[:, j]) for j, k in enumerate(keys)}
-    if g == "covariance-matrix":  # M:541 population covariance of the unique steps
+    if g == "covariance-matrix":  # M:541: (lplist-covariance unique-steps)
         u = np.array([[p[k] for k in keys] for p in walker_get(walker, ":unique-steps", take, chain=chain)])
-        return np.cov(u.T, bias=True).reshape(len(keys), len(keys))
+        return lplist_covariance(u)
     if g == "stddev-params":  # M:525-539 diagonal of the l-matrix
         if cap < 10:
             return {k: 0.0 for k in keys}

@@ -84,3 +84,15 @@ def test_lisp_shim_binds_every_header_symbol():
                 assert depth >= 0, (f, s[:i].count("\n") + 1)
             i += 1
         assert depth == 0, f
+
+
+def test_the_library_in_the_tree_was_built_from_the_sources_in_the_tree():
+    """mhx_build_id() = the hash of csrc/ as it is now: a stale libmhx.so (the .so travels to the
+    GPU box as a built file) would otherwise pass or fail the GPU suite for the wrong sources,
+    and bench.py would pair its timings with another build's instruction counts"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import source_id
+    from importlib import import_module
+    capi = import_module("lisp-mcmc_amd._capi")
+    assert capi.lib().mhx_build_id().decode() == source_id.source_id()

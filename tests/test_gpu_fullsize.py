@@ -117,20 +117,47 @@ def test_c2_full_batch_walks_like_small_batch_and_oracle(mhx, orc, c2):
 def test_c5_per_gpu_share_65536_chains(mhx, orc, c2):
     """BASELINE config 5 puts 524288 chains on 8 GPUs = 65536 per GPU.  One rank's share, taken
     from the MIDDLE of the global id range (rank 3: ids 196608...), with the pooled-covariance
-    mode the multi-GPU bench uses: chains must coincide with an 8-chain engine owning the same
-    global ids, and every chain must have moved the same number of steps."""
-    C_, n_it, off = 65536, 12, 3 * 65536
+    mode the multi-GPU bench uses, THROUGH the first pooled tick (iteration 200: statistics of
+    all 65536 chains, reduction, factorisation on the engine's stream): chains must coincide
+    with an 8-chain engine owning the same global ids (a pooled factor is first adopted at
+    iteration 400, M:929's cadence), every chain must have moved the same number of steps, and
+    the pooled factor must be the Cholesky factor of the covariance its statistics describe."""
+    C_, n_it, off = 65536, 212, 3 * 65536
     rng = np.random.Generator(np.random.Philox(key=99))
     th0 = c2.theta_star[None, :] * (1.0 + 0.01 * rng.standard_normal((C_, c2.d)))
     big = c2.engine(mhx, C_, seed=21, chain_offset=off, adapt_mode=mhx.capi.ADAPT_POOLED)
     big.init_chains(th0)
     big.adaptive_begin(30000, 10.0, 1)
-    assert big.adaptive_advance(n_it) == C_
+    assert big.adaptive_advance(12) == C_
+    assert big.pooled()["refreshes"] == 0
+    assert big.adaptive_advance(n_it - 12) == C_     # ... across the tick at iteration 200
     sb = big.state()
     assert (sb["age"] == n_it + 1).all() and big.counters()[0] == C_ * n_it
     assert np.isfinite(sb["logpost"]).all()
     st, _ = big.chain_status()
     assert (st == mhx.capi.CHAIN_RUNNING).all()
+    # the tick: (n, sum delta, sum delta delta^T) over all chains -> covariance -> (2.38^2/d) chol
+    pool = big.pooled()
+    d = c2.d
+    assert pool["refreshes"] == 1 and pool["valid"]
+    n = pool["stats"][0]
+    assert n == np.floor(n) and n > C_                # displacement count: an exact integer
+    mean = pool["stats"][1:1 + d] / n
+    cov = pool["stats"][1 + d:].reshape(d, d) / n - np.outer(mean, mean)
+    want = (2.38 ** 2 / d) * np.linalg.cholesky(cov)
+    assert np.allclose(pool["L"], want, rtol=1e-9, atol=1e-18)
+    # ... the two halves of the share, as two engines, see the same statistics between them
+    halves = np.zeros(1 + d + d * d)
+    for h in range(2):
+        e = c2.engine(mhx, C_ // 2, seed=21, chain_offset=off + h * (C_ // 2),
+                      adapt_mode=mhx.capi.ADAPT_POOLED)
+        e.init_chains(th0[h * (C_ // 2):(h + 1) * (C_ // 2)])
+        e.adaptive_begin(30000, 10.0, 1)
+        e.adaptive_advance(200)
+        halves += e.pooled()["stats"]
+        e.close()
+    assert halves[0] == n
+    assert np.allclose(halves, pool["stats"], rtol=1e-11, atol=1e-18)
     for lo in (0, 40000, C_ - 8):
         small = c2.engine(mhx, 8, seed=21, chain_offset=off + lo, adapt_mode=mhx.capi.ADAPT_POOLED)
         small.init_chains(th0[lo:lo + 8])

@@ -72,21 +72,25 @@ def test_create_destroy_does_not_leak_device_memory(mhx):
     assert free0 - free1 < 32 << 20, (free0, free1)   # each engine holds ~170 MB while alive
 
 
-def test_finished_chains_give_up_their_slots_without_changing_anything(mhx):
+@pytest.mark.parametrize("pooled", [False, True])
+def test_finished_chains_give_up_their_slots_without_changing_anything(mhx, pooled):
     """Complete walker-adaptive-steps runs of 200 chains end at different loop indices; launches
     with more workgroups than the GPU holds at once are repacked between launches with the chains
     still walking (compact_slots; MHX_COMPACT_ALWAYS=1 makes it happen for this small one too).
-    A chain's walk must not depend on it: the same run with MHX_NO_COMPACT=1."""
+    A chain's walk must not depend on it: the same run with MHX_NO_COMPACT=1.  In both adaptation
+    modes: the pooled statistics index chains, not wave slots, so the pooled factors - and with
+    them every chain - are the same wherever the chains walk."""
     import os
     os.environ["MHX_COMPACT_ALWAYS"] = "1"
     s = pb.two_peak(n=1200, seed=3)
     th0 = pb.perturbed(s.theta_star, 200, 0.01, seed=4)
+    mode = mhx.capi.ADAPT_POOLED if pooled else mhx.capi.ADAPT_FAITHFUL
     out = []
     for flag in ("1", None):
         if flag:
             os.environ["MHX_NO_COMPACT"] = flag
         try:
-            e = s.engine(mhx, 200, seed=21)
+            e = s.engine(mhx, 200, seed=21, adapt_mode=mode)
             e.init_chains(th0)
             e.adaptive_begin(6000, 10.0, 1)
             left = 1
@@ -94,6 +98,8 @@ def test_finished_chains_give_up_their_slots_without_changing_anything(mhx):
                 left = e.adaptive_advance(250)   # many launches: many chances to repack
             st = e.state()
             out.append((st, e.lmatrix(), e.chain_status()[0], e.acceptance(1000)))
+            if pooled:
+                assert e.pooled()["refreshes"] >= 10 and e.pooled()["valid"]
             e.close()
         finally:
             os.environ.pop("MHX_NO_COMPACT", None)

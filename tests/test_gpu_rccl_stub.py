@@ -1,0 +1,254 @@
+"""The communicator branch of the multi-GPU group (mhx_group_create -> ncclCommInitAll, one
+ncclAllReduce per engine inside ncclGroupStart/End on the engines' own streams) on the ONE GPU a
+test box has.  The real librccl wants a device per rank, so these tests run libmhx against the
+stand-in of tests/stub_rccl (same eight entry points and calling conventions, host-staged sum in
+rank order; MHX_RCCL_LIBRARY selects it, MHX_GROUP_FORCE_RCCL=1 lets engines that share a device
+take the branch).  libmhx opens its RCCL once per process, so every case is a child process.
+
+Also here: the process-exit regression of round 2 (a full-suite process that had used RCCL and
+hiprtc aborted with `double free or corruption` after its work was done, while librccl was opened
+RTLD_GLOBAL) - one child process with the REAL library, torch imported, asserting exit status 0."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+STUB = os.path.join(HERE, "stub_rccl", "librccl_stub.so")
+
+PRELUDE = """
+import os, sys
+sys.path[:0] = [%r, %r]
+import numpy as np
+import lisp_mcmc_amd as mhx
+import problems as pb
+
+def walk(obj, th0, iters, l_matrix=None, chunk=150):
+    obj.init_chains(th0)
+    obj.adaptive_begin(30000, 10.0, 1, l_matrix=l_matrix)
+    left = iters
+    while left > 0:
+        obj.adaptive_advance(min(left, chunk))
+        left -= chunk
+    return obj.state()
+""" % (ROOT, HERE)
+
+
+def run_child(body, tmp_path, stub=True, force=True, fail=None, extra_env=None):
+    log = tmp_path / "rccl_calls.log"
+    env = dict(os.environ, MHX_SPLIT="0")
+    env.pop("MHX_STUB_RCCL_FAIL", None)
+    if stub:
+        assert os.path.exists(STUB), "tests/stub_rccl/librccl_stub.so is not built (__graft_entry__.build())"
+        env["MHX_RCCL_LIBRARY"] = STUB
+        env["MHX_STUB_RCCL_LOG"] = str(log)
+    if force:
+        env["MHX_GROUP_FORCE_RCCL"] = "1"
+    if fail:
+        env["MHX_STUB_RCCL_FAIL"] = fail
+    env.update(extra_env or {})
+    out = subprocess.run([sys.executable, "-c", PRELUDE + textwrap.dedent(body)],
+                         capture_output=True, text=True, env=env, timeout=600)
+    calls = log.read_text().splitlines() if log.exists() else []
+    return out, calls
+
+
+def test_two_engines_through_the_communicator_branch(tmp_path):
+    """group of two engines, pooled mode, ncclCommInitAll + grouped ncclAllReduce (stub):
+    * bit for bit the group whose pool vectors are summed by libmhx itself through the host
+      (group_pool_sum_local adds in rank order too) over six ticks, pooled factors adopted;
+    * one engine holding all chains: same walk until the first pooled factor is adopted, pooled
+      statistics equal up to the order of the additions;
+    * the call pattern a multi-GPU node will see."""
+    out, calls = run_child("""
+        s = pb.two_peak(n=2000, seed=5)
+        C_ = 64
+        th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=7)
+        mode = mhx.capi.ADAPT_POOLED
+        l0 = np.diag(0.01 * np.abs(s.theta_star))
+        g = mhx.Group(C_, s.d, s.K, devices=[0, 0], seed=11, adapt_mode=mode)
+        s.apply(g)
+        e = s.engine(mhx, C_, seed=11, adapt_mode=mode)
+        a, b = walk(e, th0, 200, l0), walk(g, th0, 200, l0)
+        assert np.array_equal(a["theta"], b["theta"]) and np.array_equal(a["age"], b["age"])
+        pe, p0, p1 = e.pooled(), g.engines[0].pooled(), g.engines[1].pooled()
+        assert pe["refreshes"] == p0["refreshes"] == p1["refreshes"] == 1
+        assert np.array_equal(p0["stats"], p1["stats"]) and np.array_equal(p0["L"], p1["L"])
+        assert pe["stats"][0] == p0["stats"][0] > C_
+        assert np.allclose(pe["stats"], p0["stats"], rtol=1e-11, atol=1e-18)
+        assert p0["valid"] and np.allclose(pe["L"], p0["L"], rtol=1e-8, atol=1e-16)
+        for _ in range(8):
+            g.adaptive_advance(150)
+        sg = g.state()
+        np.save(os.environ["OUT_NPY"], np.concatenate([sg["theta"].ravel(), sg["logpost"],
+                                                       sg["age"].astype(float),
+                                                       g.engines[1].pooled()["stats"]]))
+        assert g.engines[0].pooled()["refreshes"] == 7
+        e.close(); g.close()
+        print("ok")
+    """, tmp_path, extra_env={"OUT_NPY": str(tmp_path / "stub.npy")})
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
+    # the same walk with libmhx's own host-staged sum between the two engines (no communicator)
+    out2, calls2 = run_child("""
+        s = pb.two_peak(n=2000, seed=5)
+        C_ = 64
+        th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=7)
+        l0 = np.diag(0.01 * np.abs(s.theta_star))
+        g = mhx.Group(C_, s.d, s.K, devices=[0, 0], seed=11, adapt_mode=mhx.capi.ADAPT_POOLED)
+        s.apply(g)
+        walk(g, th0, 200, l0)
+        for _ in range(8):
+            g.adaptive_advance(150)
+        sg = g.state()
+        np.save(os.environ["OUT_NPY"], np.concatenate([sg["theta"].ravel(), sg["logpost"],
+                                                       sg["age"].astype(float),
+                                                       g.engines[1].pooled()["stats"]]))
+        g.close()
+        print("ok")
+    """, tmp_path, stub=False, force=False, extra_env={"OUT_NPY": str(tmp_path / "local.npy")})
+    assert out2.returncode == 0 and "ok" in out2.stdout, out2.stderr[-3000:]
+    import numpy as np
+    assert np.array_equal(np.load(tmp_path / "stub.npy"), np.load(tmp_path / "local.npy"))
+    # call pattern: one communicator per engine from ONE ncclCommInitAll; per tick a group of
+    # exactly two all-reduces of 1 + d + d^2 doubles; both communicators destroyed at close
+    assert calls[0] == "CommInitAll ndev=2 devices=0,0"
+    ticks = [i for i, c in enumerate(calls) if c.startswith("GroupStart")]
+    assert len(ticks) == 7
+    for i in ticks:
+        assert calls[i] == "GroupStart depth=1"
+        assert calls[i + 1].startswith("AllReduce rank=0 comm_device=0 current_device=0 count=73 in_group=1")
+        assert calls[i + 2].startswith("AllReduce rank=1 comm_device=0 current_device=0 count=73 in_group=1")
+        assert calls[i + 3] == "GroupEnd depth=0 pending=2"
+        assert calls[i + 4] == "flush clique_of=2 count=73 rc=0"
+    assert [c for c in calls if c.startswith("CommDestroy")] == [
+        "CommDestroy rank=0 device=0", "CommDestroy rank=1 device=0"]
+
+
+@pytest.mark.parametrize("where", ["allreduce", "groupend"])
+def test_a_failing_collective_surfaces_as_ecomm_and_ends_the_run(tmp_path, where):
+    out, calls = run_child("""
+        s = pb.two_peak(n=1500, seed=5)
+        C_ = 32
+        th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=7)
+        g = mhx.Group(C_, s.d, s.K, devices=[0, 0], seed=3, adapt_mode=mhx.capi.ADAPT_POOLED)
+        s.apply(g)
+        g.init_chains(th0)
+        g.adaptive_begin(30000, 10.0, 1)
+        g.adaptive_advance(199)                      # no tick yet: nothing collective has run
+        try:
+            g.adaptive_advance(1)
+            raise SystemExit("the failing collective went unnoticed")
+        except mhx.MhxError as ex:
+            assert ex.code == mhx.capi.ECOMM, ex
+            assert "nccl" in str(ex), ex
+        try:                                         # the run is over: host and device
+            g.adaptive_advance(1)                    # bookkeeping may have come apart
+            raise SystemExit("advance after a failed tick")
+        except mhx.MhxError as ex:
+            assert ex.code == mhx.capi.ESTATE, ex
+        st = g.state()
+        assert (st["age"] == 201).all()              # the 200 iterations themselves were taken
+        g.adaptive_begin(30000, 10.0, 1)             # ... and a new run may begin
+        g.adaptive_advance(10)
+        g.close()
+        print("ok")
+    """, tmp_path, fail=where)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
+    i = calls.index("GroupStart depth=1")
+    # every ncclGroupStart is paired with an ncclGroupEnd, also when a call in between failed
+    assert any(c.startswith("GroupEnd depth=0") for c in calls[i + 1:i + 4]), calls[i:i + 5]
+
+
+def test_comm_init_all_failure_is_reported_by_group_create(tmp_path):
+    out, calls = run_child("""
+        s = pb.two_peak(n=1500, seed=5)
+        try:
+            mhx.Group(32, s.d, s.K, devices=[0, 0], seed=3, adapt_mode=mhx.capi.ADAPT_POOLED)
+            raise SystemExit("group created without a communicator")
+        except mhx.MhxError as ex:
+            assert ex.code == mhx.capi.ECOMM and "ncclCommInitAll" in str(ex), ex
+        # the per-walker mode needs no communicator at all
+        g = mhx.Group(32, s.d, s.K, devices=[0, 0], seed=3)
+        g.close()
+        print("ok")
+    """, tmp_path, fail="initall")
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
+    assert calls == ["CommInitAll ndev=2 FAIL(injected)"]
+
+
+def test_one_rank_communicator_on_the_stub(tmp_path):
+    """mhx_comm_init_rank's path (one process per GPU): ungrouped ncclAllReduce on the engine's
+    stream between the statistics kernels and the factorisation"""
+    out, calls = run_child("""
+        s = pb.two_peak(n=2000, seed=6)
+        C_ = 32
+        th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=8)
+        mode = mhx.capi.ADAPT_POOLED
+        plain = s.engine(mhx, C_, seed=12, adapt_mode=mode)
+        comm = s.engine(mhx, C_, seed=12, adapt_mode=mode)
+        comm.comm_init_rank(mhx.comm_unique_id(), 0, 1)
+        a, b = walk(plain, th0, 700), walk(comm, th0, 700)
+        for k in ("theta", "logpost", "age"):
+            assert np.array_equal(a[k], b[k]), k
+        assert plain.pooled()["refreshes"] == comm.pooled()["refreshes"] == 3
+        plain.close(); comm.close()
+        print("ok")
+    """, tmp_path, force=False)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
+    assert calls[0].startswith("GetUniqueId") and calls[1].startswith("CommInitRank")
+    assert sum(c.startswith("AllReduce rank=0") and c.endswith("in_group=0") for c in calls) == 3
+    assert calls[-1].startswith("CommDestroy")
+
+
+def test_a_librccl_of_another_hip_runtime_is_refused(tmp_path):
+    """MHX_RCCL_LIBRARY pointing at something that is not an RCCL: the loader says why instead of
+    crashing later (and a library bound to a second HIP runtime is refused the same way, by
+    comparing the address both sides resolve hipStreamSynchronize to)"""
+    out, _ = run_child("""
+        try:
+            mhx.comm_unique_id()
+            raise SystemExit("no error")
+        except mhx.MhxError as ex:
+            assert ex.code == mhx.capi.ECOMM and "RCCL unavailable" in str(ex), ex
+        print("ok")
+    """, tmp_path, stub=False, force=False,
+                       extra_env={"MHX_RCCL_LIBRARY": os.path.join(ROOT, "oracle", "libmhx_oracle.so")})
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
+
+
+def test_process_with_rccl_and_hiprtc_exits_cleanly(tmp_path):
+    """round 2's exit abort, pinned: torch imported, a run-time compiled expression model (hiprtc +
+    comgr loaded), the REAL librccl in a 1-rank communicator, engines left for the interpreter's
+    exit to collect.  While librccl was opened RTLD_GLOBAL such processes ended in `double free
+    or corruption (!prev)` after their work was done; opened RTLD_LOCAL they exit 0."""
+    out, _ = run_child("""
+        import torch
+        s = pb.two_peak(n=2000, seed=6)
+        C_ = 32
+        th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=8)
+        mode = mhx.capi.ADAPT_POOLED
+        rc = s.engine(mhx, C_, seed=12, adapt_mode=mode)
+        rc.comm_init_rank(mhx.comm_unique_id(), 0, 1)     # real ncclCommInitRank
+        plain = s.engine(mhx, C_, seed=12, adapt_mode=mode)
+        a, b = walk(plain, th0, 450), walk(rc, th0, 450)  # two ticks through ncclAllReduce
+        assert np.array_equal(a["theta"], b["theta"])
+        ex = s.engine(mhx, 8, seed=1)
+        keys, cexpr = mhx.sexpr.lambda_to_expr(
+            "(lambda (x &key b0 b1 a1 mu1 w1 a2 mu2 w2 &allow-other-keys)"
+            " (+ (+ b0 (* b1 x)) (* a1 (exp (- (expt (/ (- x mu1) w1) 2))))"
+            "    (* a2 (exp (- (expt (/ (- x mu2) w2) 2))))))")
+        ex.set_function_expr(0, cexpr, keys, list(range(8)))   # hiprtc
+        ex.init_chains(th0[:8])
+        assert "rtc" in ex.kernel_name()
+        assert torch.cuda.is_available()
+        print("ok", flush=True)
+        # no close(): what is alive here is torn down by the interpreter and the libraries' own
+        # exit handlers, as at the end of a pytest process
+    """, tmp_path, stub=False, force=False)
+    assert "ok" in out.stdout, out.stderr[-3000:]
+    assert out.returncode == 0, (out.returncode, out.stderr[-3000:])

@@ -75,3 +75,24 @@ def test_saved_walker_text_roundtrip_without_gpu(mhx, tmp_path):
     assert full["data"] == [[[-4.0, -1.0, 2.0], [0.0, 2.0, 5.0]]] and full["stddev"] == [[0.2, 0.2, 0.2]]
     assert mhx.saveload._d(1e-7) == "1.0d-7" and mhx.saveload._d(2.5) == "2.5d0"
     assert mhx.walker_load(str(p), quiet=True) is None     # no designators: recommendations only
+
+
+def _orc_cov(orc, v):
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    out = np.zeros((v.shape[1], v.shape[1]))
+    assert orc.lib().orc_lplist_covariance(v.ctypes.data_as(orc.f64p), v.shape[0], v.shape[1],
+                                           out.ctypes.data_as(orc.f64p)) == 0
+    return out
+
+
+def test_lplist_covariance_python_equals_the_pinned_oracle(orc):
+    """host mirror of lplist-covariance = the oracle's (which reproduces the reference's own
+    known answer M:745), bit for bit, also on ill-conditioned input"""
+    from importlib import import_module
+    lplist_covariance = import_module("lisp-mcmc_amd.walker").lplist_covariance
+    rng = np.random.default_rng(3)
+    for n, d in ((5, 3), (2, 2), (333, 8), (1000, 6)):
+        v = rng.standard_normal((n, d)) * 10.0 ** rng.integers(-6, 6, d) + rng.standard_normal(d) * 1e3
+        assert np.array_equal(lplist_covariance(v), _orc_cov(orc, v)), (n, d)
+
+

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Round 2's exit abort, looked at once more with the old dlopen flags (diagnostics; run by hand
+on a GPU box: `python3 tools/debug/rccl_exit_abort.py > gpurun_out/rccl_exit_abort.txt 2>&1`).
+
+Four full-suite pytest processes of round 2 ended in `double free or corruption (!prev)` /
+`free(): invalid pointer` AFTER pytest had printed its summary, while libmhx opened librccl with
+RTLD_GLOBAL (| RTLD_NODELETE); none since it opens it RTLD_LOCAL.  This script runs the same
+ingredients in child processes - hiprtc-compiled model, real librccl in a 1-rank communicator,
+engines left to the interpreter's exit - with MHX_RCCL_DLOPEN_GLOBAL=1 (the old flags) and
+without, under an LD_PRELOADed SIGABRT handler that prints the C backtrace and the mapped
+HIP/RCCL/compiler libraries.  It prints each child's exit status; it asserts nothing."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CHILD = r"""
+import os, sys
+sys.path[:0] = [%r, %r]
+import numpy as np
+order = os.environ["ORDER"]
+import lisp_mcmc_amd as mhx
+import problems as pb
+s = pb.two_peak(n=2000, seed=6)
+th0 = pb.perturbed(s.theta_star, 32, 0.01, seed=8)
+keep = []
+def rccl():
+    e = s.engine(mhx, 32, seed=12, adapt_mode=mhx.capi.ADAPT_POOLED)
+    e.comm_init_rank(mhx.comm_unique_id(), 0, 1)
+    e.init_chains(th0); e.adaptive_begin(30000, 10.0, 1); e.adaptive_advance(450)
+    keep.append(e)
+def rtc():
+    e = s.engine(mhx, 8, seed=1)
+    keys, cexpr = mhx.sexpr.lambda_to_expr(
+        "(lambda (x &key b0 b1 a1 mu1 w1 a2 mu2 w2 &allow-other-keys)"
+        " (+ (+ b0 (* b1 x)) (* a1 (exp (- (expt (/ (- x mu1) w1) 2))))"
+        "    (* a2 (exp (- (expt (/ (- x mu2) w2) 2))))))")
+    e.set_function_expr(0, cexpr, keys, list(range(8)))
+    e.init_chains(th0[:8]); e.kernel_name()
+    keep.append(e)
+def torch_():
+    import torch
+    torch.zeros(4, device="cuda").sum().item()
+for step in order.split(","):
+    {"rccl": rccl, "rtc": rtc, "torch": torch_}[step]()
+print("work done:", order, flush=True)
+""" % (ROOT, os.path.join(ROOT, "tests"))
+
+
+def main():
+    so = os.path.join(HERE, "abort_bt.so")
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", so, os.path.join(HERE, "abort_bt.c")])
+    for glob in ("1", "0"):
+        for order in ("rccl", "rtc,rccl", "rccl,rtc", "rtc,rccl,torch", "torch,rccl,rtc"):
+            env = dict(os.environ, ORDER=order, MHX_RCCL_DLOPEN_GLOBAL=glob, LD_PRELOAD=so,
+                       MHX_SPLIT="0")
+            r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True,
+                               timeout=600)
+            print("==== RTLD_%s order=%s -> exit status %d" % ("GLOBAL|NODELETE" if glob == "1" else "LOCAL",
+                                                             order, r.returncode))
+            if r.returncode != 0:
+                print(r.stdout[-500:])
+                print(r.stderr[-6000:])
+            sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    main()

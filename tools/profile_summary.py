@@ -10,20 +10,33 @@ import os
 import sys
 
 
-def counters(d, kernel_substr):
+def dispatch_ids(root, kern):
+    """Dispatch ids of the k_adaptive launches in launch order (kernel trace of the stats pass):
+    bench.py names the timed region and the direct-form launch by their position in it."""
+    ids = []
+    for f in glob.glob(os.path.join(root, "stats", "**", "*_kernel_trace.csv"), recursive=True):
+        rows = [r for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"]]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        ids = rows
+    return ids
+
+
+def counters(d, kernel_substr, first, last):
+    """counter sums over the k_adaptive dispatches [first, last) of the pass under d (every pass
+    is the same command: the same sequence of dispatches)"""
     out = {}
     for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         per = {}
         for r in csv.DictReader(open(f)):
             if kernel_substr in r["Kernel_Name"]:
-                key = (int(r["Dispatch_Id"]), r["Counter_Name"])
-                per[key] = per.get(key, 0.0) + float(r["Counter_Value"])
-        if not per:
-            continue
-        last = max(k[0] for k in per)  # the timed launch is the last dispatch of the kernel
-        for (disp, name), v in per.items():
-            if disp == last:
-                out[name] = v
+                per.setdefault(int(r["Dispatch_Id"]), {})
+                c = per[int(r["Dispatch_Id"])]
+                c[r["Counter_Name"]] = c.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        order = sorted(per)
+        for disp in order[first:last]:
+            for name, v in per[disp].items():
+                out[name] = out.get(name, 0.0) + v
+        out["_dispatches_in_pass"] = len(order)
     return out
 
 
@@ -31,33 +44,52 @@ def main():
     root = sys.argv[1]
     kern = "k_adaptive"
     res = {"dir": os.path.basename(root)}
-    for f in glob.glob(os.path.join(root, "stats", "**", "*_kernel_stats.csv"), recursive=True):
-        rows = list(csv.DictReader(open(f)))
-        res["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")}
-                               for r in rows[:6]]
-    for f in glob.glob(os.path.join(root, "stats", "**", "*_kernel_trace.csv"), recursive=True):
-        rows = [r for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"]]
-        if rows:
-            r = rows[-1]
-            res["timed_launch"] = {"duration_ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
-                                   "vgpr": r.get("VGPR_Count"), "sgpr": r.get("SGPR_Count"),
-                                   "lds": r.get("LDS_Block_Size"), "scratch": r.get("Scratch_Size"),
-                                   "grid": r.get("Grid_Size_X"), "workgroup": r.get("Workgroup_Size_X")}
-    c = {}
-    for sub in ("fetch", "write", "sq", "lds"):
-        c.update(counters(os.path.join(root, sub), kern))
-    res["pmc_timed_launch"] = c
-    if "FETCH_SIZE" in c:
-        res["hbm_read_bytes"] = c["FETCH_SIZE"] * 1024 * 2  # gfx950 correction (guide, HBM section)
-    if "WRITE_SIZE" in c:
-        res["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
+    bench = {}
     for name in ("bench_stats.json", "bench_unprofiled.json"):
         p = os.path.join(root, name)
         if os.path.exists(p) and os.path.getsize(p):
             try:
-                res[name[:-5]] = json.loads(open(p).read().strip().splitlines()[-1])
+                bench[name[:-5]] = json.loads(open(p).read().strip().splitlines()[-1])
             except Exception as ex:  # noqa
-                res[name[:-5]] = "unparsed: %s" % ex
+                bench[name[:-5]] = "unparsed: %s" % ex
+    bs = bench.get("bench_stats") if isinstance(bench.get("bench_stats"), dict) else {}
+    trace = dispatch_ids(root, kern)
+    # which dispatches are the timed region / the direct-form launch: bench.py says
+    # (older lines: the last dispatch)
+    timed = (bs.get("roofline") or {}).get("timed_dispatches") or [len(trace) - 1, len(trace)]
+    direct = (bs.get("direct_form") or {}).get("dispatches")
+    res["k_adaptive_dispatches"] = len(trace)
+    for f in glob.glob(os.path.join(root, "stats", "**", "*_kernel_stats.csv"), recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        res["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")}
+                               for r in rows[:6]]
+
+    def launch_info(span):
+        rows = trace[span[0]:span[1]]
+        if not rows:
+            return None
+        r = rows[-1]
+        return {"dispatches": list(span),
+                "duration_ns": sum(int(q["End_Timestamp"]) - int(q["Start_Timestamp"]) for q in rows),
+                "vgpr": r.get("VGPR_Count"), "sgpr": r.get("SGPR_Count"),
+                "lds": r.get("LDS_Block_Size"), "scratch": r.get("Scratch_Size"),
+                "grid": r.get("Grid_Size_X"), "workgroup": r.get("Workgroup_Size_X")}
+    res["timed_launch"] = launch_info(timed)
+    c = {}
+    for sub in ("fetch", "write", "sq", "lds"):
+        c.update(counters(os.path.join(root, sub), kern, timed[0], timed[1]))
+    res["pmc_timed_launch"] = c
+    if direct:
+        res["direct_launch"] = launch_info(direct)
+        cd = {}
+        for sub in ("sq", "lds"):
+            cd.update(counters(os.path.join(root, sub), kern, direct[0], direct[1]))
+        res["pmc_direct_launch"] = cd
+    if "FETCH_SIZE" in c:
+        res["hbm_read_bytes"] = c["FETCH_SIZE"] * 1024 * 2  # gfx950 correction (guide, HBM section)
+    if "WRITE_SIZE" in c:
+        res["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
+    res.update(bench)
     print(json.dumps(res, indent=1))
 
 

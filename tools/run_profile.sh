@@ -4,7 +4,7 @@
 # <name> = <round>_<workload>_s<steps>_w<warmup> (what bench.py looks for under profiles/).
 # Usage: tools/run_profile.sh <round tag> <workload> <steps> <warmup> [more bench args...]
 set -e
-TAG=${1:-r02}; WL=${2:-c2}; ST=${3:-200}; WU=${4:-200}; shift 4 || true
+TAG=${1:-r03}; WL=${2:-c2}; ST=${3:-200}; WU=${4:-200}; shift 4 || true
 NAME=${TAG}_${WL}_s${ST}_w${WU}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT/gpurun_out/prof_$NAME
@@ -22,12 +22,19 @@ find $R/stats -name "*_kernel_stats.csv" -exec cp {} $GRAFT_REPO_ROOT/gpurun_out
 python3 - <<PY
 import json
 d = json.load(open("$R/summary.json"))
-t, p = d.get("timed_launch", {}), d.get("pmc_timed_launch", {})
+t, p = d.get("timed_launch") or {}, d.get("pmc_timed_launch", {})
 b = d.get("bench_stats", {})
-pts = b["roofline"]["iterations_per_launch"] * b["config"]["chains_per_gpu"] * b["config"]["n_points"]
+pts = b["steps"] * b["config"]["chains_per_gpu"] * b["config"]["n_points"]
 ipp = p.get("SQ_INSTS_VALU", 0) * 64.0 / pts
 dur = t.get("duration_ns", 0) * 1e-9
-print("$NAME: timed launch %.3f ms, vgpr %s scratch %s, %.2f VALU instr/point, VALU issue frac @2.4GHz %.3f, value %.4g"
-      % (dur * 1e3, t.get("vgpr"), t.get("scratch"), ipp,
-         p.get("SQ_INSTS_VALU", 0) * 4 / (1024 * 2.4e9 * dur) if dur else 0, b.get("value", 0)))
+print("$NAME [%s]: timed region %.3f ms (dispatches %s of %s), vgpr %s scratch %s, %.2f VALU instr/point, "
+      "VALU issue frac @2.4GHz %.3f, SALU/VALU %.3f, value %.4g"
+      % (b.get("build", {}).get("id"), dur * 1e3, t.get("dispatches"), d.get("k_adaptive_dispatches"),
+         t.get("vgpr"), t.get("scratch"), ipp,
+         p.get("SQ_INSTS_VALU", 0) * 4 / (1024 * 2.4e9 * dur) if dur else 0,
+         p.get("SQ_INSTS_SALU", 0) / max(p.get("SQ_INSTS_VALU", 1), 1), b.get("value", 0)))
+dl, pd = d.get("direct_launch"), d.get("pmc_direct_launch", {})
+if dl:
+    print("  direct form: %.3f ms, %.2f VALU instr/point, value_direct_form %.4g"
+          % (dl["duration_ns"] * 1e-6, pd.get("SQ_INSTS_VALU", 0) * 64.0 / pts, b.get("value_direct_form", 0)))
 PY
