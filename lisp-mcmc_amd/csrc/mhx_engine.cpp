@@ -96,17 +96,21 @@ struct Rccl {
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
 };
-// The library is opened RTLD_LOCAL, and that is load-bearing.  Both librccl builds on a ROCm
-// machine (the ROCm installation's and the one PyTorch wheels bundle) export, next to the nccl*
-// entry points, several hundred C++ symbols of global visibility: weak std:: template
-// instantiations and fmt::v7's STB_GNU_UNIQUE data.  Opened RTLD_GLOBAL they join the process's
-// global scope, and every library loaded LATER (hiprtc / comgr for a run-time compiled model, a
-// second HIP user in the same image) binds its own weak copies of those symbols to RCCL's; at
-// exit both sides destroy what each takes to be its own object: `double free or corruption
-// (!prev)` / `free(): invalid pointer` after the work was done (round 2: four full-suite runs
-// with RTLD_GLOBAL [| RTLD_NODELETE] ended that way, none since; DESIGN.md section 6,
-// tests/test_gpu_rccl_stub.py::test_process_with_rccl_and_hiprtc_exits_cleanly).
-// MHX_RCCL_DLOPEN_GLOBAL=1 restores the old flags - for tools/debug/rccl_exit_abort.py only.
+// The library is opened RTLD_LOCAL, and that is load-bearing.  What is known (DESIGN.md
+// section 6): four full-suite test processes of round 2 that had used RCCL and hiprtc ended in
+// `double free or corruption (!prev)` / `free(): invalid pointer` AFTER their work was done,
+// while this dlopen said RTLD_GLOBAL (later RTLD_GLOBAL | RTLD_NODELETE) - with the ROCm
+// installation's librccl as well as with the one PyTorch bundles; none of the dozens of runs
+// since it says RTLD_LOCAL has.  Both builds of librccl export, next to the nccl* entry points,
+// several hundred C++ symbols of default visibility - weak std:: template instantiations and
+// fmt::v7's STB_GNU_UNIQUE data objects (`nm -D`) - which RTLD_GLOBAL adds to the scope every
+// LATER-loaded library's own weak symbols are resolved in; two libraries tearing down what each
+// takes for its own object at exit is the mechanism that fits, but it is NOT established: the
+// old flags with RCCL and hiprtc in one process, in three load orders, exit cleanly
+// (tools/debug/rccl_exit_abort.py, round 3).  So the flag is kept local, nothing of RCCL's is
+// ever visible to anybody but this file's dlsym calls, and one test keeps a process with RCCL,
+// hiprtc and torch at exit status 0 (tests/test_gpu_rccl_stub.py).
+// MHX_RCCL_DLOPEN_GLOBAL=1 restores the old flags - for that debug script only.
 std::string g_rccl_why;  // why rccl().ok is false
 Rccl& rccl() {
   static Rccl r;

@@ -121,13 +121,17 @@ def test_c5_per_gpu_share_65536_chains(mhx, orc, c2):
     all 65536 chains, reduction, factorisation on the engine's stream): chains must coincide
     with an 8-chain engine owning the same global ids (a pooled factor is first adopted at
     iteration 400, M:929's cadence), every chain must have moved the same number of steps, and
-    the pooled factor must be the Cholesky factor of the covariance its statistics describe."""
+    the pooled factor must be the Cholesky factor of the covariance its statistics describe.
+    (The walk starts from a small :l-matrix: from the default diag(theta) of M:899 hardly a chain
+    has accepted anything by iteration 200, and a covariance of fewer displacements than
+    parameters has no Cholesky factor - the tick then rightly reports `valid = 0`.)"""
     C_, n_it, off = 65536, 212, 3 * 65536
+    l0 = np.diag(0.01 * np.abs(c2.theta_star))
     rng = np.random.Generator(np.random.Philox(key=99))
     th0 = c2.theta_star[None, :] * (1.0 + 0.01 * rng.standard_normal((C_, c2.d)))
     big = c2.engine(mhx, C_, seed=21, chain_offset=off, adapt_mode=mhx.capi.ADAPT_POOLED)
     big.init_chains(th0)
-    big.adaptive_begin(30000, 10.0, 1)
+    big.adaptive_begin(30000, 10.0, 1, l_matrix=l0)
     assert big.adaptive_advance(12) == C_
     assert big.pooled()["refreshes"] == 0
     assert big.adaptive_advance(n_it - 12) == C_     # ... across the tick at iteration 200
@@ -152,7 +156,7 @@ def test_c5_per_gpu_share_65536_chains(mhx, orc, c2):
         e = c2.engine(mhx, C_ // 2, seed=21, chain_offset=off + h * (C_ // 2),
                       adapt_mode=mhx.capi.ADAPT_POOLED)
         e.init_chains(th0[h * (C_ // 2):(h + 1) * (C_ // 2)])
-        e.adaptive_begin(30000, 10.0, 1)
+        e.adaptive_begin(30000, 10.0, 1, l_matrix=l0)
         e.adaptive_advance(200)
         halves += e.pooled()["stats"]
         e.close()
@@ -161,7 +165,7 @@ def test_c5_per_gpu_share_65536_chains(mhx, orc, c2):
     for lo in (0, 40000, C_ - 8):
         small = c2.engine(mhx, 8, seed=21, chain_offset=off + lo, adapt_mode=mhx.capi.ADAPT_POOLED)
         small.init_chains(th0[lo:lo + 8])
-        small.adaptive_begin(30000, 10.0, 1)
+        small.adaptive_begin(30000, 10.0, 1, l_matrix=l0)
         small.adaptive_advance(n_it)
         ss = small.state()
         assert np.array_equal(sb["theta"][lo:lo + 8], ss["theta"]), lo
@@ -169,7 +173,7 @@ def test_c5_per_gpu_share_65536_chains(mhx, orc, c2):
         small.close()
     op = c2.oracle(orc)
     w = orc.Walker(op, th0[40001])
-    w.adaptive_begin(30000, 10.0, 1, seed=21, chain_id=off + 40001)
+    w.adaptive_begin(30000, 10.0, 1, l_matrix=l0, seed=21, chain_id=off + 40001)
     w.adaptive_advance(n_it)
     assert np.array_equal(sb["theta"][40001], w.last()[0])
     big.close()

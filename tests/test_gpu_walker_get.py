@@ -39,7 +39,7 @@ def test_unique_steps_param_covariance_stddev_from_the_device_trace(mhx, orc):
                           data_error=sig,
                           log_prior=mhx.prior_bounds({keys[i]: (lo[i], hi[i]) for i in idx}),
                           seed=41, history_capacity=4096)
-    ow = orc.Walker(op, th0)
+    ow = orc.Walker(op, th0, mirror=True)  # the kernels' own arithmetic: probs equal to the bit
     assert w.last_step().prob == ow.last()[1]
     # a young walker: :stddev-params is all zeros below 10 steps (M:528-529)
     assert mhx.walker_get(w, get=":stddev-params") == {k: 0.0 for k in keys}
@@ -58,6 +58,7 @@ def test_unique_steps_param_covariance_stddev_from_the_device_trace(mhx, orc):
         assert len(uniq) == len(keep)
         got = np.array([[p[k] for k in keys] for p in uniq])
         assert np.array_equal(got, oth[keep]), take
+        assert mhx.walker_get(w, get=":log-liklihoods", take=take) == oprob.tolist()
         # :param (M:509)
         for j in (0, 3, 7):
             col = mhx.walker_get(w, get=":param", take=take, param=":" + keys[j])

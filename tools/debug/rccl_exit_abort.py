@@ -53,11 +53,11 @@ def main():
     so = os.path.join(HERE, "abort_bt.so")
     subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", so, os.path.join(HERE, "abort_bt.c")])
     for glob in ("1", "0"):
-        for order in ("rccl", "rtc,rccl", "rccl,rtc", "rtc,rccl,torch", "torch,rccl,rtc"):
+        for order in ("rccl", "rtc,rccl", "rccl,rtc"):  # (a torch step after these hung under the preload)
             env = dict(os.environ, ORDER=order, MHX_RCCL_DLOPEN_GLOBAL=glob, LD_PRELOAD=so,
                        MHX_SPLIT="0")
             r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True,
-                               timeout=600)
+                               timeout=120)
             print("==== RTLD_%s order=%s -> exit status %d" % ("GLOBAL|NODELETE" if glob == "1" else "LOCAL",
                                                              order, r.returncode))
             if r.returncode != 0:
