@@ -130,7 +130,6 @@ __device__ __forceinline__ void tile_prio(int sec, int it) {
 #ifndef MHX_PRIO_LADDER
 #define MHX_PRIO_LADDER 0
 #endif
-  const int g = sec * NIN + it;  // iteration of the tile (`it` is a constant after unrolling)
 #if MHX_PRIO_LADDER
   // (levels after 1/2, 3/4 and 7/8 of the tile - a shorter last level: no gain on config 2 and
   // -5 % on config 3 against quarters, measured)
@@ -138,11 +137,20 @@ __device__ __forceinline__ void tile_prio(int sec, int it) {
 #else
   constexpr int b1 = NIT / 4, b2 = NIT / 2, b3 = 3 * NIT / 4;  // a level per quarter of the tile
 #endif
-  static_assert(NIT >= 2 && (NIN & (NIN - 1)) == 0, "sections of 2^k iterations");
-  if (g == 0) __builtin_amdgcn_s_setprio(3);
-  else if (g == b1) __builtin_amdgcn_s_setprio(2);
-  else if (g == b2) __builtin_amdgcn_s_setprio(1);
-  else if (g == b3) __builtin_amdgcn_s_setprio(0);
+  static_assert(NIT >= 2 && (NIN & (NIN - 1)) == 0 && NIT % NIN == 0, "sections of 2^k iterations");
+  // iteration g = sec * NIN + it of the tile starts a level when g is one of 0, b1, b2, b3.  `it`
+  // is a constant after unrolling and `sec` is not, so the test is written per SECTION: what is
+  // left of it in the code is one scalar compare of `sec` in front of each s_setprio (the
+  // arithmetic form, g == b, came out as a vector shift and a vector compare per boundary:
+  // +1.3 % on config 2, same box).
+#pragma unroll
+  for (int s = 0; s < NIT / NIN; ++s) {
+    const int g = s * NIN + it;
+    if (g == 0) { if (sec == s) __builtin_amdgcn_s_setprio(3); }
+    else if (g == b1) { if (sec == s) __builtin_amdgcn_s_setprio(2); }
+    else if (g == b2) { if (sec == s) __builtin_amdgcn_s_setprio(1); }
+    else if (g == b3) { if (sec == s) __builtin_amdgcn_s_setprio(0); }
+  }
 #endif
 }
 
@@ -345,7 +353,13 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
           }
 #pragma unroll
           for (int it = 0; it < NIN; ++it) {
-            if (wb + it * P * kWave >= nv) break;  // uniform: one scalar compare per P points
+            // uniform: one scalar compare per P points.  (Round 3: compiled out for datasets of
+            // whole windows - neutral / masked pads make it unnecessary there - the all-recurrence
+            // variants ran 1.5 % SLOWER and the direct-form variants spilled 624 B per lane: the
+            // branch is what keeps the unrolled iterations apart for the register allocator, and
+            // with four waves per SIMD the scalar instructions ride in issue slots the vector
+            // pipe leaves free.  It stays.)
+            if (wb + it * P * kWave >= nv) break;
             tile_prio<NIT, NIN>(sec, it);
             double xn[P], yn[P], wn[P], cn[P];
 #pragma unroll
