@@ -415,6 +415,10 @@ int finalize_problem(mhx_engine* e) {
     FnDesc& f = e->P.fn[k];
     f.user_slot = f.prior_slot = -1;
     f.tile_skip = tile_skip;
+    {  // MHX_NO_YW=1: the shared-tile layout with x for every step (A/B runs; same bits either way)
+      const char* ny = getenv("MHX_NO_YW");
+      f.no_yw = (ny && atoi(ny) != 0) ? 1 : 0;
+    }
     if (f.lik == MHX_LIK_EXPR) {
       if (e->lik_expr[k].empty())
         return fail(MHX_ESTATE, "dataset %d uses MHX_LIK_EXPR but mhx_set_likelihood_expr was "

@@ -163,6 +163,177 @@ struct CMask {
   constexpr operator unsigned() const { return M; }
 };
 
+// ---- "yw" tiles: steps in which nobody reads x ---------------------------------------------
+// Once a walk has settled, every peak of every chain of a workgroup advances by the uniform-grid
+// recurrence and the background with them (Prep::bgrec): such a sweep reads y/sigma and 1/sigma
+// and, at the start of each 2048-point window, ONE x per lane (the seed).  The x tile - a third
+// of the LDS-DMA traffic and of the tile buffers - is dead weight then.  When every running chain
+// of the workgroup is in that state (one vote per sweep: sweep()), the same LDS holds two-array
+// tiles of TWICE the points: half the tile barriers and pipeline restarts per sweep, a third less
+// DMA; the seeds' x come straight from L2, fetched one tile ahead.  Per lane and window the
+// operations and their order are those of sweep()'s all-recurrence variants (same seeds at the
+// same points, same masks, even points to acc0 and odd to acc1): the SAME BITS whichever layout a
+// step takes (tests/test_gpu_families.py::test_yw_tiles_give_the_same_bits; MHX_NO_YW=1 switches
+// the layout off).
+template <class Model, int LIK>
+struct yw_capable {
+  static constexpr bool value = false;
+};
+template <int NBG, int NPK, int LIK>
+struct yw_capable<PeaksModel<NBG, NPK, false>, LIK> {
+  typedef PeaksModel<NBG, NPK, false> M;
+  static constexpr bool value = LIK == MHX_LIK_NORMAL && M::kHasSkip && M::kHasRec && NPK <= 2 &&
+                                M::kSeedSteps == kPadPoints / kWave && MHX_PPI == 2;
+};
+
+template <class Model, int LIK>
+__device__ __forceinline__ double sweep_yw(const FnDesc& f, const typename Model::Prep& prep,
+                                           bool active, GroupLds& lds) {
+  constexpr int P = 2;
+  constexpr int T2 = 2 * kTilePoints;           // points of a yw tile: 4096 (w16), 2048 (w8)
+  constexpr int WPT = T2 / kPadPoints;          // windows per yw tile: 2 (w16), 1 (w8)
+  constexpr int NITW = kPadPoints / kWave / P;  // iterations of a lane per window
+  constexpr int NIN = NITW > 8 ? 8 : NITW;      // ... in sections of at most 8 unrolled ones
+  constexpr int NSEC = NITW / NIN;
+  static_assert(WPT >= 1 && T2 % kPadPoints == 0 && NITW % NIN == 0, "whole windows per yw tile");
+  static_assert(2 * 2 * T2 <= 2 * kMaxArrays * kTilePoints, "the yw tiles live in GroupLds::tiles");
+  constexpr unsigned kAll = (1u << Model::kPeaks) - 1u;
+  const int l = lane_id();
+  const int w = wave_in_group();
+  const int64_t nw = (f.n + kPadPoints - 1) / kPadPoints;  // windows of the dataset (>= 1)
+  const int64_t nt2 = (nw + WPT - 1) / WPT;
+  double* const base = &lds.tiles[0][0][0];  // buffer b: y at base + 2 b T2, 1/sigma at + T2
+  // yw tile j -> buffer b: two LDS-DMA instructions per array and thread (16 B each); the arrays
+  // are padded to whole windows, so the second half of the last tile may not exist
+  auto dma = [&](int64_t j, int b) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int64_t p0 = j * T2 + (int64_t)q * kTilePoints;
+      if (p0 < nw * kPadPoints) {  // uniform
+        const int64_t g = p0 + 2 * (int)threadIdx.x;
+        const int dst = q * kTilePoints + 2 * kWave * w;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(f.y + g),
+                                         (lds_ptr_t)(base + (2 * b) * T2 + dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(f.w + g),
+                                         (lds_ptr_t)(base + (2 * b + 1) * T2 + dst), 16, 0, 0);
+      }
+    }
+  };
+  // the lane's x at the first point of each window of tile j (what the recurrence is seeded from)
+  auto load_xs = [&](int64_t j, double (&xs)[WPT]) {
+#pragma unroll
+    for (int q = 0; q < WPT; ++q) {
+      const int64_t wi = j * WPT + q;
+      xs[q] = f.x[(wi < nw ? wi : nw - 1) * kPadPoints + l];
+    }
+  };
+  double acc0 = 0.0, acc1 = 0.0;
+  double xs[WPT], xs_next[WPT];
+  unsigned tile_masks = ~0u;
+  dma(0, 0);
+  load_xs(0, xs);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) lds.vote[3] = 0;  // (the vote of sweep(): everybody has read it)
+  for (int64_t j = 0; j < nt2; ++j) {
+    const int b = (int)(j & 1);
+    if (j + 1 < nt2) {
+      dma(j + 1, b ^ 1);  // (that buffer was last read in tile j - 1: everybody left it through the barrier)
+      load_xs(j + 1, xs_next);
+    }
+    if (active) {
+#pragma unroll
+      for (int q = 0; q < WPT; ++q) {
+        const int64_t wi = j * WPT + q;
+        if (wi >= nw) break;
+        if ((wi & 63) == 0) {  // the masks of 64 windows at once, lane i taking window wi + i
+          const int64_t ti = wi + l < nw ? wi + l : nw - 1;
+          tile_masks = Model::tile_mask(prep, f.txlo[ti], f.txhi[ti]);
+        }
+        // (no guarded window can occur: the vote asked for Prep::fast, |t| < kFastT over the
+        // whole x range, of which every window's range is a part)
+        const unsigned tm =
+            (unsigned)__builtin_amdgcn_readlane((int)tile_masks, (int)(wi & 63)) & kAll;
+        lds_cdptr_t py[P], pw[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {  // (opaque: see tile_work in sweep())
+          py[i] = opaque_lds((lds_cdptr_t)(base + (2 * b) * T2 + q * kPadPoints) + i * kWave + l);
+          pw[i] = opaque_lds((lds_cdptr_t)(base + (2 * b + 1) * T2 + q * kPadPoints) + i * kWave + l);
+        }
+        const int64_t left = f.n - wi * (int64_t)kPadPoints;
+        const int nv = (int)(left < (int64_t)kPadPoints ? left : (int64_t)kPadPoints);
+        const double x0 = xs[q];
+        auto window = [&](auto mk) {
+          const unsigned mask = mk;
+          typename Model::Rec rs;
+#pragma unroll 1
+          for (int sec = 0; sec < NSEC; ++sec) {
+            const int sb = sec * NIN * P * kWave;  // first point of the section in the window
+            if (sb >= nv) break;
+            double y[P], wv[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+              y[i] = py[i][sb];
+              wv[i] = pw[i][sb];
+            }
+#pragma unroll
+            for (int it = 0; it < NIN; ++it) {
+              if (sb + it * P * kWave >= nv) break;  // (uniform; it also keeps the iterations apart)
+              tile_prio<WPT * NITW, NIN>(q * NSEC + sec, it);
+              double yn[P], wn[P];
+#pragma unroll
+              for (int i = 0; i < P; ++i) {
+                yn[i] = wn[i] = 0.0;
+                if (it + 1 < NIN) {
+                  yn[i] = py[i][sb + (it + 1) * P * kWave];
+                  wn[i] = pw[i][sb + (it + 1) * P * kWave];
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the arithmetic below
+              if (it == 0 && sec == 0) {  // seeded at the lane's first point of the window
+                if (mask != 0u) Model::rec_seed(prep, x0, mask, rs);
+                Model::rec_seed_bg(prep, x0, rs);
+              }
+              const double xu[P] = {x0, x0};  // (not read: background and peaks by recurrence)
+              double m[P];
+              Model::template eval_mixed<P, true>(prep, xu, mask, mask, rs, m);
+#pragma unroll
+              for (int i = 0; i < P; ++i) {
+                double& acc = (i & 1) ? acc1 : acc0;
+                const double r = __builtin_fma(-m[i], wv[i], y[i]);
+                acc = __builtin_fma(r, r, acc);
+              }
+#pragma unroll
+              for (int i = 0; i < P; ++i) {
+                y[i] = yn[i];
+                wv[i] = wn[i];
+              }
+            }
+          }
+        };
+        if constexpr (Model::kPeaks == 1) {
+          if (tm & 1u) window(CMask<1u>{}); else window(CMask<0u>{});
+        } else {
+          switch (tm) {
+            case 0u: window(CMask<0u>{}); break;
+            case 1u: window(CMask<1u>{}); break;
+            case 2u: window(CMask<2u>{}); break;
+            default: window(CMask<3u>{}); break;
+          }
+        }
+      }
+    }
+#ifndef MHX_NO_TILE_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of tile j + 1 has landed
+    __syncthreads();                                   // ... and so has everybody else's
+#pragma unroll
+    for (int q = 0; q < WPT; ++q) xs[q] = xs_next[q];
+  }
+  return wave_sum(acc0 + acc1);
+}
+
 // Sum over the points of function f.  Collective over the workgroup (barriers inside);
 // waves with active == false only help to move tiles.  fast (wave-uniform): this chain's
 // parameters satisfy the model's fast-path precondition (model_has_fast) - decided per WAVE:
@@ -204,6 +375,20 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
   // latency-bound walk (+9 % on a single chain; with hundreds of chains it measured slower, so
   // the engine sets FnDesc::solo only there).
   const bool solo = f.solo != 0;
+  // Which tile layout this sweep takes is a decision of the WORKGROUP (the tiles are shared): the
+  // yw tiles when no running chain needs x beyond its seeds.  A wave that needs x raises a flag,
+  // one barrier, everybody reads it; the flag is lowered again behind the first tile barrier
+  // (every reader is past it by then, and the next vote only comes after this sweep's last one).
+  if constexpr (yw_capable<Model, LIK>::value) {
+    if (!solo && f.no_yw == 0) {
+      constexpr unsigned kAllPeaks = (1u << model_peaks<Model>::value) - 1u;
+      const bool mine = !active || (fast && bgrec && rmask == kAllPeaks);
+      if (!mine && lane_id() == 0) lds.vote[3] = 1;
+      __syncthreads();
+      if (__builtin_amdgcn_readfirstlane(*(volatile int*)&lds.vote[3]) == 0)
+        return sweep_yw<Model, LIK>(f, prep, active, lds);
+    }
+  }
   const bool have = solo && __builtin_amdgcn_readfirstlane(lds.resident) != 0;
   // (every wave must have looked at the flag before the first one through the block below sets
   // it: a wave that arrived late and read 1 would skip the block - its part of the DMA and the
@@ -217,6 +402,9 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (solo && threadIdx.x == 0) lds.resident = 1;
     __syncthreads();
+    if constexpr (yw_capable<Model, LIK>::value) {
+      if (threadIdx.x == 0) lds.vote[3] = 0;  // (the layout vote above)
+    }
   }
   MHX_TIM(lds, 3);
   // Between the two tiles of a window (8-wave family): everybody is through with tile `tcur`

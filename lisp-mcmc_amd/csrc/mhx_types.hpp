@@ -54,6 +54,8 @@ struct FnDesc {
   int32_t solo;        // 1: the problem's only function and a single tile - it stays in LDS
   int32_t user_slot;  // >= 0: index of the run-time compiled expression model (MHX_MODEL_EXPR)
   int32_t prior_slot; // >= 0: index of the run-time compiled prior body, else -1
+  int32_t no_yw;      // 1: never take the two-array "yw" tiles of the all-recurrence steps (MHX_NO_YW=1)
+  int32_t pad_;
 };
 
 struct ProblemDesc {

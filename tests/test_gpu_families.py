@@ -107,3 +107,61 @@ def test_resident_single_tile_repeated_launches(mhx, orc):
                 got = e.logpost(th)
                 assert np.all(np.abs(got - ref) <= 1e-12 * scale), (e.kernel_name(), chains, rep)
             e.close()
+
+
+@pytest.mark.parametrize("n", [1500, 2048, 4097, 5000, 12288, 100000])
+@pytest.mark.parametrize("wpg", ["8", "16"])
+def test_yw_tiles_give_the_same_bits(mhx, orc, n, wpg):
+    """Steps in which every running chain of a workgroup advances all its peaks and the
+    background by the recurrence take two-array tiles of twice the points (sweep_yw: y/sigma and
+    1/sigma only, seeds' x straight from L2; decided per sweep by a workgroup vote).  The layout
+    must not show in any bit: against MHX_NO_YW=1 and against the oracle's mirror, for datasets of
+    one window, whole windows, a ragged last window, an odd and an even number of windows, in
+    both kernel families, on log-posteriors and on walks (where chains of one workgroup leave and
+    re-enter the all-recurrence state from proposal to proposal)."""
+    s = pb.two_peak(n=n, seed=40 + n % 7)
+    op = s.oracle(orc)
+    C_ = 37
+    th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=3)
+    out = []
+    os.environ["MHX_FAMILY_WPG"] = wpg
+    try:
+        for flag in ("1", None):
+            if flag:
+                os.environ["MHX_NO_YW"] = flag
+            try:
+                e = s.engine(mhx, C_, seed=8)
+                e.init_chains(th0)  # finalises the problem under these settings
+            finally:
+                os.environ.pop("MHX_NO_YW", None)
+            out.append(e)
+    finally:
+        os.environ.pop("MHX_FAMILY_WPG", None)
+    a, b = out
+    th = pb.perturbed(s.theta_star, 64, 0.02, seed=4)     # all-recurrence vectors: yw tiles
+    th[5, 4] = 1e-4                                        # ... but for a few: a narrow peak,
+    th[21, 7] = -0.03                                      # a negative width,
+    th[40, 3] = 7.5                                        # a centre far outside the data
+    ga, gb = a.logpost(th), b.logpost(th)
+    assert np.array_equal(ga, gb)
+    for c in (0, 1, 5, 21, 40, 63):
+        assert gb[c] == op.logpost_mirror(th[c]), (n, wpg, c)
+    l0 = np.diag(0.003 * np.abs(s.theta_star))
+    for e in (a, b):
+        e.adaptive_begin(900, 10.0, 1, l_matrix=l0)
+        e.adaptive_advance(1 << 40)
+    sa, sb = a.state(), b.state()
+    for k in ("theta", "logpost", "best_logpost", "age", "length"):
+        assert np.array_equal(sa[k], sb[k]), (n, wpg, k)
+    assert np.array_equal(a.lmatrix(), b.lmatrix())
+    # ... and from the default diag(theta) start, where proposals are wild and the chains of a
+    # workgroup disagree about the layout most of the time
+    for e in (a, b):
+        e.init_chains(th0)
+        e.adaptive_begin(30000, 10.0, 1)
+        e.adaptive_advance(60)
+    sa, sb = a.state(), b.state()
+    for k in ("theta", "logpost", "age"):
+        assert np.array_equal(sa[k], sb[k]), (n, wpg, k)
+    a.close()
+    b.close()
