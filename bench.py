@@ -254,6 +254,10 @@ def main():
                     help="GPU time spent on a throw-away engine of the same kernel before the walk's "
                          "warm-up launch, so that the timed launch runs at the clock the chip holds "
                          "under this load (0: off)")
+    ap.add_argument("--devices", default="",
+                    help="one-process runs: the device of each of the --gpus engines, comma separated "
+                         "(default 0..N-1).  Naming a device twice rehearses the N-GPU code path on "
+                         "fewer GPUs (with MHX_GROUP_FORCE_RCCL=1 and a stand-in librccl: tests/stub_rccl)")
     ap.add_argument("--no-direct", action="store_true",
                     help="skip the second, short measurement with the uniform-grid recurrence off")
     args = ap.parse_args()
@@ -278,9 +282,13 @@ def main():
 
     devices = [local_rank] if per_rank else list(range(n_gpus))
     if not per_rank:
+        if args.devices:
+            devices = [int(v) for v in args.devices.split(",")]
+            if len(devices) != n_gpus:
+                raise SystemExit("--devices names %d devices for --gpus %d" % (len(devices), n_gpus))
         have = torch.cuda.device_count()
-        if have < n_gpus:
-            raise SystemExit("--gpus %d but this process sees %d GPU(s)" % (n_gpus, have))
+        if have <= max(devices):
+            raise SystemExit("device %d asked for but this process sees %d GPU(s)" % (max(devices), have))
 
     as_expr = args.workload == "c2expr"  # config 2 with the model given as a Lisp closure text
     spec, chains, b_pt, desc = synth_workload("c2" if as_expr else args.workload)
@@ -350,7 +358,7 @@ def main():
     l0 = np.diag(0.002 * np.abs(spec.theta_star)) if args.workload == "c3" else None
 
     def sync():
-        for dv in devices:
+        for dv in sorted(set(devices)):
             torch.cuda.synchronize(dv)
         if dist is not None:
             dist.barrier()
@@ -491,7 +499,10 @@ def main():
                    "adaptation": ("pooled covariance, all-reduce of %d doubles / 200 iterations" % (1 + spec.d + spec.d ** 2))
                    if pooled else "faithful per-walker (no collective)",
                    "parallelism": ("chains sharded over %d GPU(s), " % n_gpus) +
-                                  ("one process per GPU" if per_rank else "one host process"),
+                                  ("one process per GPU" if per_rank else "one host process") +
+                                  ("" if len(set(devices)) == len(devices) else
+                                   " [REHEARSAL: %d engines on %d physical device(s)]"
+                                   % (len(devices), len(set(devices)))),
                    **({"collective": collective} if collective else {}),
                    "clock_spin": ("%.0f ms of the same kernel on a throw-away engine before the walk's "
                                   "warm-up launch" % spin_ms) if spin_ms else "none",

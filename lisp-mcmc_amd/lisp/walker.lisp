@@ -319,6 +319,12 @@ not the state of every chain)"
            (take (max 1 take)))
       (cffi:with-foreign-objects ((pr :double take) (th :double (* take d)) (n-out :int))
         (with-c-call (check (%mhx-get-trace e c take pr th n-out)))
+        ;; the reference keeps every step of a walk (M:549), the engine the newest
+        ;; history-capacity in its device ring: a window that reaches past the ring is answered
+        ;; with what is there, and says so
+        (when (< (cffi:mem-ref n-out :int) take)
+          (warn "walker-get :take ~d: the device history ring holds the newest ~d steps of this walk; create the walker with :history-capacity >= the walk's length to keep them all"
+                take (cffi:mem-ref n-out :int)))
         (loop for s below (cffi:mem-ref n-out :int)
               collect (make-walker-step
                        :prob (cffi:mem-aref pr :double s)

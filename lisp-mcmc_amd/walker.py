@@ -24,6 +24,8 @@ list of walkers sequentially, M:1029-1033); `chain=` selects a member on read-ba
 """
 from fractions import Fraction
 
+import warnings
+
 import numpy as np
 
 from . import _capi as capi
@@ -356,6 +358,10 @@ def _percentile(n, seq):  # nth-percentile M:1493-1504
     return float((copy[lo] + copy[lo + 1]) / 2)
 
 
+class HistoryTruncated(UserWarning):
+    """walker-get was asked about more steps than the device history ring still holds"""
+
+
 def lplist_covariance(v):
     """lplist-covariance M:614-643 of N parameter vectors [N, d], in the reference's own order of
     operations: averages (/ (reduce #'+ x) N) M:626, then per entry the serial sum over the points
@@ -393,6 +399,14 @@ def walker_get(walker, get=":steps", take=None, param=None, chain=0):
             raise FloatingPointError("(walker-get :l-matrix): floating-point-invalid-operation")
         return L if st == capi.L_OK else np.zeros((0, 0))
     prob, th = e.trace(chain, t)
+    if len(prob) < t:
+        # the reference keeps every step of a walk (M:549); the engine keeps the newest
+        # history_capacity in its device ring.  A window that reaches past the ring is answered
+        # with what is there - and says so, instead of silently being about a shorter walk.
+        warnings.warn(HistoryTruncated(
+            "walker-get %s :take %d: the device history ring holds the newest %d of the walk's %d "
+            "steps; create the walker with history_capacity >= the walk's length to keep them all"
+            % (get, t, len(prob), cap)), stacklevel=2)
     steps = [walker._step(th[i], prob[i]) for i in range(len(prob))]
     if g == "steps":
         return steps

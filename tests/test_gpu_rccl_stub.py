@@ -252,3 +252,60 @@ def test_process_with_rccl_and_hiprtc_exits_cleanly(tmp_path):
     """, tmp_path, stub=False, force=False)
     assert "ok" in out.stdout, out.stderr[-3000:]
     assert out.returncode == 0, (out.returncode, out.stderr[-3000:])
+
+
+def test_bench_gpus_2_in_one_process_rehearsed_on_one_gpu(tmp_path):
+    """`python3 bench.py --gpus 2` without a launcher: ONE process, mhx.Group over two engines,
+    pooled adaptation with the tick's collective inside the timed region - rehearsed here with
+    both engines on device 0 and the stand-in librccl.  One JSON line, whole-job rate, the
+    contract's fields."""
+    import json
+    env = dict(os.environ, MHX_RCCL_LIBRARY=STUB, MHX_GROUP_FORCE_RCCL="1",
+               MHX_STUB_RCCL_LOG=str(tmp_path / "calls.log"))
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    env.pop("MHX_SPLIT", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0",
+                          "--chains", "512", "--steps", "200", "--warmup", "200", "--no-cpu",
+                          "--spin-ms", "5"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 200 and d["warmup"] == 200 and d["scaling"] == "weak"
+    assert d["config"]["chains_per_gpu"] == 512 and "ncclCommInitAll" in d["config"]["collective"]
+    assert "one host process" in d["config"]["parallelism"]
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] * 1e-3 / (2 * 512) - 1.0) < 1e-9
+    assert len(d["roofline"]["kernel_ms_per_gpu"]) == 2
+    calls = (tmp_path / "calls.log").read_text().splitlines()
+    assert calls[0] == "CommInitAll ndev=2 devices=0,0"
+    # warm-up ends on the tick at iteration 200, the timed region on the one at 400: one tick each
+    assert sum(c.startswith("GroupStart") for c in calls) == 2
+
+
+@pytest.mark.skipif("__import__('torch').cuda.device_count() < 2")
+def test_two_real_gpus_walk_like_two_engines_on_one():
+    """(runs only where two GPUs are visible) Group(devices=[0, 1]) through the REAL librccl
+    against Group(devices=[0, 0]) through libmhx's host-staged sum: the same chains, pooled
+    statistics equal up to the order of the two additions."""
+    import numpy as np
+    import lisp_mcmc_amd as mhx
+    import problems as pb
+    s = pb.two_peak(n=2000, seed=5)
+    C_ = 64
+    th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=7)
+    l0 = np.diag(0.01 * np.abs(s.theta_star))
+    res = []
+    for devs in ([0, 1], [0, 0]):
+        g = mhx.Group(C_, s.d, s.K, devices=devs, seed=11, adapt_mode=mhx.capi.ADAPT_POOLED)
+        s.apply(g)
+        g.init_chains(th0)
+        g.adaptive_begin(30000, 10.0, 1, l_matrix=l0)
+        for _ in range(4):
+            g.adaptive_advance(150)
+        res.append((g.state(), g.engines[0].pooled(), g.engines[1].pooled()))
+        g.close()
+    (sa, a0, a1), (sb, b0, b1) = res
+    assert np.array_equal(a0["stats"], a1["stats"]) and a0["refreshes"] == b0["refreshes"] == 3
+    assert np.allclose(a0["stats"], b0["stats"], rtol=1e-12, atol=1e-18)
+    assert (sa["age"] == sb["age"]).all() and np.isfinite(sa["logpost"]).all()

@@ -74,3 +74,23 @@ def test_unique_steps_param_covariance_stddev_from_the_device_trace(mhx, orc):
         sd = mhx.walker_get(w, get=":stddev-params", take=take)
         assert [sd[k] for k in keys] == [L[j, j] for j in range(8)], take
     assert len(uniq) < ow.length  # (the walk did reject proposals: the selectors had work to do)
+
+
+def test_a_window_beyond_the_history_ring_is_signalled(mhx):
+    """the reference keeps every step (M:549); the device ring keeps the newest history_capacity
+    (default 1024): asking for more returns what is there AND warns"""
+    import warnings
+    from lisp_mcmc_amd.walker import HistoryTruncated
+    lf_x, lf_y = [-4, -1, 2, 5, 10], [0, 2, 5, 9, 13]
+    w = mhx.walker_create(function=mhx.models.line("b", "m"), data=[lf_x, lf_y],
+                          params=[":b", -1, ":m", 2], data_error=0.2, seed=3)
+    mhx.walker_many_steps(w, 1500, l_matrix=np.diag([0.05, 0.02]))
+    assert w.length() == 1501
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert len(mhx.walker_get(w, get=":steps", take=1024)) == 1024   # inside the ring: silent
+    with pytest.warns(HistoryTruncated):
+        steps = mhx.walker_get(w, get=":steps")                           # the whole walk: 1501
+    assert len(steps) == 1024
+    with pytest.warns(HistoryTruncated):
+        mhx.walker_get(w, get=":median-params", take=1200)

@@ -76,13 +76,13 @@ def main():
                 "grid": r.get("Grid_Size_X"), "workgroup": r.get("Workgroup_Size_X")}
     res["timed_launch"] = launch_info(timed)
     c = {}
-    for sub in ("fetch", "write", "sq", "lds"):
+    for sub in ("fetch", "write", "ic", "sq", "lds"):
         c.update(counters(os.path.join(root, sub), kern, timed[0], timed[1]))
     res["pmc_timed_launch"] = c
     if direct:
         res["direct_launch"] = launch_info(direct)
         cd = {}
-        for sub in ("sq", "lds"):
+        for sub in ("ic", "sq", "lds"):
             cd.update(counters(os.path.join(root, sub), kern, direct[0], direct[1]))
         res["pmc_direct_launch"] = cd
     if "FETCH_SIZE" in c:

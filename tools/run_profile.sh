@@ -15,6 +15,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/fetch -- python3 /root/repo
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/write -- python3 /root/repo/bench.py $ARGS > /dev/null 2> $R/write.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/sq -- python3 /root/repo/bench.py $ARGS > /dev/null 2> $R/sq.err
 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/lds -- python3 /root/repo/bench.py $ARGS > /dev/null 2> $R/lds.err || true
+rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $R/ic -- python3 /root/repo/bench.py $ARGS > /dev/null 2> $R/ic.err || true
 python3 /root/repo/bench.py $ARGS > $R/bench_unprofiled.json 2>/dev/null
 python3 /root/repo/tools/profile_summary.py $R > $R/summary.json
 cp $R/summary.json $GRAFT_REPO_ROOT/gpurun_out/${NAME}_summary.json
