@@ -639,11 +639,13 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
                             int logfact_double) {
   double local[MHX_MAX_FN_PARAMS];
   gather(f, theta, local);
-  if (f->model != MHX_MODEL_GAUSS_PEAKS || (f->lik != MHX_LIK_NORMAL && f->lik != MHX_LIK_POISSON)) {
+  if (f->model != MHX_MODEL_GAUSS_PEAKS ||
+      (f->lik != MHX_LIK_NORMAL && f->lik != MHX_LIK_POISSON && f->lik != MHX_LIK_NORMAL_CUTOFF)) {
     *supported = 0;
     return NAN;
   }
   const int poisson = f->lik == MHX_LIK_POISSON;
+  const int cutoff = f->lik == MHX_LIK_NORMAL_CUTOFF; /* log-liklihood-normal-cutoff M:419-427 */
   const int nbg = f->shape[0], npk = f->shape[1];
   const double ksl2e = 1.2011224087864497594; /* sqrt(log2 e) */
   double iw[MHX_MAX_FN_PARAMS], cc[MHX_MAX_FN_PARAMS], A[MHX_MAX_FN_PARAMS];
@@ -780,6 +782,18 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
           continue;
         }
         const double rr = fma(-m, w, yw);
+        if (cutoff) {
+          /* sweep<>, MHX_LIK_NORMAL_CUTOFF: the point's own constant c_i = -1/2 log 2 pi - log
+           * sigma_i (mhx_set_dataset) inside the term, (max -5000d0 term) M:426, plain adds */
+          const double ci = half_log_2pi + (-1.0 * log(s));
+          const double tt = fma(-0.5 * rr, rr, ci);
+          const double tc = tt > -5000.0 ? tt : -5000.0;
+          if (kk & 1)
+            acc1[lane] = acc1[lane] + tc;
+          else
+            acc0[lane] = acc0[lane] + tc;
+          continue;
+        }
         if (kk & 1)
           acc1[lane] = fma(rr, rr, acc1[lane]);
         else
@@ -800,6 +814,7 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
     }
     return v[0] + (double)csum;
   }
+  if (cutoff) return v[0]; /* finish_lik<MHX_LIK_NORMAL_CUTOFF>: the constants sit in the terms */
   return fma(-0.5, v[0], (double)csum);
 }
 

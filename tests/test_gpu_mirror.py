@@ -213,3 +213,36 @@ def test_poisson_walk_equals_mirror(mhx, orc):
         assert st["age"][c] == w.age
         assert np.array_equal(st["theta"][c], th) and st["logpost"][c] == pr, c
     e.close()
+
+
+@pytest.mark.parametrize("n", [1, 65, 1024, 2049, 5000, 100000])
+def test_cutoff_logpost_and_walk_equal_mirror(mhx, orc, n):
+    """log-liklihood-normal-cutoff (M:419-427; BASELINE names it beside the weighted normal
+    likelihood): the four-array kernel (x, y/sigma, 1/sigma, the point's constant) bit for bit
+    against the oracle's restatement, clamped terms included, on log-posteriors and on a walk"""
+    s = pb.two_peak(n=n, seed=200 + n, lik=pb.CUTOFF)
+    op = s.oracle(orc)
+    e = s.engine(mhx, 3, seed=17)
+    assert "cutoff" in e.kernel_name()
+    th = pb.perturbed(s.theta_star, 13, 0.03, seed=n)
+    th[1] = s.theta_star * 1.7
+    th[2, 2] = 40.0
+    th[3, 4] = 1e-3
+    got, parts = e.logpost(th, parts=True)
+    for i, t in enumerate(th):
+        ref, rp = op.logpost_mirror(t, parts=True)
+        assert got[i] == ref and parts[i, 0] == rp[0] and parts[i, 1] == rp[1], (n, i)
+    th0 = pb.perturbed(s.theta_star, 3, 0.01, seed=4)
+    n_it = 700 if n <= 5000 else 150  # (the CPU side walks 3 x n_it x n points)
+    e.init_chains(th0)
+    e.adaptive_begin(n_it, 10.0, 1)
+    e.adaptive_advance(1 << 40)
+    st = e.state()
+    for c in range(3):
+        w = orc.Walker(op, th0[c], mirror=True)
+        w.adaptive_begin(n_it, 10.0, 1, seed=17, chain_id=c)
+        w.adaptive_advance(1 << 40)
+        th_w, pr_w = w.last()
+        assert np.array_equal(st["theta"][c], th_w) and st["logpost"][c] == pr_w, (n, c)
+        assert st["age"][c] == w.age
+    e.close()

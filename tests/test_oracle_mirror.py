@@ -99,3 +99,22 @@ def test_bounds_prior_far_outside_the_box(orc):
     a, pa = op.logpost(t, parts=True)
     b, pm = op.logpost_mirror(t, parts=True)
     assert np.isfinite(pa[1]) and np.isfinite(pm[1]) and abs(pa[1] / pm[1] - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("n", [1, 65, 1000, 1025, 5000, 100000])
+def test_cutoff_mirror_within_tolerance_of_faithful(orc, n):
+    """log-liklihood-normal-cutoff (M:419-427, each term clamped at -5000) in the kernel's
+    arithmetic against the faithful restatement - with points whose terms ARE clamped"""
+    s = pb.two_peak(n=n, seed=n + 5, lik=pb.CUTOFF)
+    op = s.oracle(orc)
+    th = pb.perturbed(s.theta_star, 6, 0.03, seed=n)
+    th[1] = s.theta_star * 1.7      # every bound violated, most terms at the clamp
+    th[2, 2] = 40.0                 # a peak 40 times too high: its points are clamped
+    clamped = 0
+    for t in th:
+        a, pa = op.logpost(t, parts=True)
+        b, pm = op.logpost_mirror(t, parts=True)
+        assert np.isfinite(b)
+        assert abs(pa[0] - pm[0]) <= REL * op.abs_terms(t)
+        clamped += pa[0] <= -5000.0
+    assert n < 65 or clamped >= 1
