@@ -552,6 +552,9 @@ struct PeaksModel {
     // one point of a lane to its next (64 grid points on); rec: usable this step
     double rm2d[NPK], rnd2[NPK], rq[NPK];
     unsigned rmask;  // bit k: peak k goes by the recurrence this step
+    // narrower peaks go by it too, re-seeded more often: bit k of s16 - also every kSeedSteps / 2
+    // points of the lane; of s8 - every kSeedSteps / 4 (a peak in s8 is in s16 as well)
+    unsigned s16, s8;
     // ... and when EVERY peak does, so does a constant or linear background (b(x + 64 h) =
     // b(x) + 64 h b1, re-seeded with the peaks): such a step never reads x beyond the seeds, which
     // takes a third off the LDS traffic of the sweep.  Decided per step, not per tile.
@@ -594,6 +597,12 @@ struct PeaksModel {
   };
   static __device__ __forceinline__ unsigned rec_mask(const Prep& p) { return p.rmask; }
   static __device__ __forceinline__ bool rec_bg(const Prep& p) { return p.bgrec; }
+  static __device__ __forceinline__ unsigned seed16(const Prep& p) { return p.s16; }
+  static __device__ __forceinline__ unsigned seed8(const Prep& p) { return p.s8; }
+  // (split mode seeds every kSeedSteps points only: the peaks of the long class, and the
+  // background with them only when that is all of them)
+  static __device__ __forceinline__ unsigned rec_mask_long(const Prep& p) { return p.rmask & ~p.s16; }
+  static __device__ __forceinline__ bool rec_bg_long(const Prep& p) { return p.bgrec && p.s16 == 0u; }
   static __device__ __forceinline__ void rec_seed_bg(const Prep& p, double x0, Rec& rs) {
     rs.b = bg_of(p, x0);
   }
@@ -823,18 +832,31 @@ struct PeaksModel {
     p.skip = skip && afin && kHasSkip;
     p.afin = afin;
     p.K.pin();
-    unsigned rmask = 0;
+    unsigned rmask = 0, s16 = 0, s8 = 0;
 #pragma unroll
     for (int k = 0; k < NPK; ++k) {
       const double dl = fn.grid_H * p.iw[k];  // D_k
       p.rm2d[k] = uniform_f64(-2.0 * dl);
       p.rnd2[k] = uniform_f64(-(dl * dl));
       p.rq[k] = uniform_f64(mexp2(2.0 * p.rnd2[k]));
-      const bool ok = kHasRec && (fast || kHasSkip) && fn.grid_H != 0.0 &&
-                      (fabs(dl) * (double)kSeedSteps <= 1.0);  // NaN fails
-      rmask |= ok ? (1u << k) : 0u;
+      // three classes by the peak's width in grid points: S |D| <= 1 for the seeding period S the
+      // peak gets (kSeedSteps, half of it, a quarter of it); NaN fails all three
+      const bool base = kHasRec && (fast || kHasSkip) && fn.grid_H != 0.0;
+      const double ad = fabs(dl);
+      const bool ok32 = base && (ad * (double)kSeedSteps <= 1.0);
+      const bool ok16 = base && (ad * (double)(kSeedSteps / 2) <= 1.0);
+      const bool ok8 = base && (ad * (double)(kSeedSteps / 4) <= 1.0);
+      rmask |= ok8 ? (1u << k) : 0u;
+      s16 |= (ok8 && !ok32) ? (1u << k) : 0u;
+      s8 |= (ok8 && !ok16) ? (1u << k) : 0u;
     }
+#ifdef MHX_ONE_SEED_CLASS  // (build knob for A/B measurements: round 2's single class)
+    rmask &= ~s16;
+    s16 = s8 = 0;
+#endif
     p.rmask = (unsigned)__builtin_amdgcn_readfirstlane((int)rmask);
+    p.s16 = (unsigned)__builtin_amdgcn_readfirstlane((int)s16);
+    p.s8 = (unsigned)__builtin_amdgcn_readfirstlane((int)s8);
     // (<= 2 peaks: with more, the second copy of the run-time-masked tile loop costs more than
     // the reads it saves - config 3: 6.1e5 -> 4.5e5 chain-steps/s, measured)
     p.bgrec = NBG >= 1 && NBG <= 2 && NPK <= 2 && p.rmask == (1u << NPK) - 1u;

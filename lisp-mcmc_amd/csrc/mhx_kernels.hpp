@@ -382,13 +382,21 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
   if constexpr (yw_capable<Model, LIK>::value) {
     if (!solo && f.no_yw == 0) {
       constexpr unsigned kAllPeaks = (1u << model_peaks<Model>::value) - 1u;
-      const bool mine = !active || (fast && bgrec && rmask == kAllPeaks);
+      bool mine = !active || (fast && bgrec && rmask == kAllPeaks);
+      mine = mine && (!active || Model::seed16(prep) == 0u);  // (seeds inside a window need x)
       if (!mine && lane_id() == 0) lds.vote[3] = 1;
       __syncthreads();
       if (__builtin_amdgcn_readfirstlane(*(volatile int*)&lds.vote[3]) == 0)
         return sweep_yw<Model, LIK>(f, prep, active, lds);
     }
   }
+  unsigned seed16 = 0u, seed8 = 0u;  // (REC) the peaks re-seeded inside a window
+  if constexpr (model_has_rec<Model>::value) {
+    seed16 = Model::seed16(prep);
+    seed8 = Model::seed8(prep);
+  }
+  (void)seed16;
+  (void)seed8;
   const bool have = solo && __builtin_amdgcn_readfirstlane(lds.resident) != 0;
   // (every wave must have looked at the flag before the first one through the block below sets
   // it: a wave that arrived late and read 1 would skip the block - its part of the DMA and the
@@ -580,6 +588,11 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
                 if ((it * P) % 16 == 0 && gp % kSeedPts == 0) {
                   if ((rm & mask) != 0u) Model::rec_seed(prep, x[0], rm & mask, rs);
                   if constexpr (BGREC) Model::rec_seed_bg(prep, x[0], rs);
+                } else if ((it * P) % (kSeedPts / 4) == 0) {
+                  // narrower peaks, seeded every kSeedPts / 2 or / 4 points of the lane
+                  // (PeaksModel::prepare): run-time masks, wave-uniform, rarely non-zero
+                  const unsigned ms = (gp % (kSeedPts / 2) == 0 ? seed16 : seed8) & rm & mask;
+                  if (ms != 0u) Model::rec_seed(prep, x[0], ms, rs);
                 }
                 Model::template eval_mixed<P, BGREC>(prep, x, mask, rm, rs, m);
               } else {
@@ -829,9 +842,9 @@ struct FixedSpec {
       if (Model::fast_ok(prep)) {
         if constexpr (model_has_rec<Model>::value &&
                       (LIK == MHX_LIK_NORMAL || LIK == MHX_LIK_POISSON)) {
-          const unsigned rmask = Model::rec_mask(prep);
+          const unsigned rmask = Model::rec_mask_long(prep);
           if (rmask != 0u) {
-            if (__builtin_amdgcn_readfirstlane((int)Model::rec_bg(prep)) != 0)
+            if (__builtin_amdgcn_readfirstlane((int)Model::rec_bg_long(prep)) != 0)
               return sweep_direct_rec<Model, LIK, true>(f, prep, p0, p1, rmask);
             return sweep_direct_rec<Model, LIK, false>(f, prep, p0, p1, rmask);
           }

@@ -678,13 +678,21 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
    * is exact for these values as well, so - as for the direct form - it is not restated. */
   const double gH = mir_grid_H(f);
   double rm2d[MHX_MAX_FN_PARAMS], rnd2[MHX_MAX_FN_PARAMS], rq[MHX_MAX_FN_PARAMS];
-  int rec[MHX_MAX_FN_PARAMS];
+  int rec[MHX_MAX_FN_PARAMS], s16[MHX_MAX_FN_PARAMS], s8[MHX_MAX_FN_PARAMS];
   for (int k = 0; k < npk; ++k) {
     const double dl = gH * iw[k];
     rm2d[k] = -2.0 * dl;
     rnd2[k] = -(dl * dl);
     rq[k] = mir_mexp2(2.0 * rnd2[k]);
-    rec[k] = (fast || has_skip) && gH != 0.0 && (fabs(dl) * (double)MIR_SEED_STEPS <= 1.0);
+    /* three classes by width (PeaksModel::prepare): S |D| <= 1 for the seeding period S = 32, 16
+     * or 8 points of a lane; a peak of a shorter class is re-seeded inside the window too */
+    const int base = (fast || has_skip) && gH != 0.0;
+    const int ok32 = base && (fabs(dl) * (double)MIR_SEED_STEPS <= 1.0);
+    const int ok16 = base && (fabs(dl) * (double)(MIR_SEED_STEPS / 2) <= 1.0);
+    const int ok8 = base && (fabs(dl) * (double)(MIR_SEED_STEPS / 4) <= 1.0);
+    rec[k] = ok8;
+    s16[k] = ok8 && !ok32;
+    s8[k] = ok8 && !ok16;
   }
   /* ... and when EVERY peak goes by the recurrence, a constant or linear background does too
    * (Prep::bgrec): b(x + 64 h) = b(x) + 64 h b1, re-seeded with the peaks */
@@ -755,6 +763,17 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
         if (i >= f->n) break;
         const double s = f->sigma[i];
         const double w = 1.0 / s, yw = f->y[i] * w, x = f->x[i];
+        /* sweep(): the narrower classes are re-seeded from the direct formulas, at the lane's
+         * actual x, every 16 (every 8) points of the lane inside the window */
+        if (kk > 0 && kk % (MIR_SEED_STEPS / 4) == 0)
+          for (int k = 0; k < npk; ++k) {
+            const int due = kk % (MIR_SEED_STEPS / 2) == 0 ? s16[k] : s8[k];
+            if (due && rec[k] && fastw && !far[k]) {
+              const double ts = fma(x, iw[k], cc[k]);
+              g[k] = mir_exp2_negsq(ts);
+              r[k] = mir_exp2_plain(fma(rm2d[k], ts, rnd2[k]));
+            }
+          }
         double m = nbg > 0 ? local[nbg - 1] : 0.0;
         if (bgrec_w) {
           m = bgv;

@@ -183,3 +183,61 @@ def test_walk_equals_mirror_with_the_recurrence(mhx, orc):
         assert st["age"][c] == w.age
         assert np.array_equal(st["theta"][c], th) and st["logpost"][c] == pr, c
     e.close()
+
+
+@pytest.mark.parametrize("wpg", ["8", "16"])
+def test_three_seeding_periods_by_peak_width(mhx, orc, wpg):
+    """Round 3: peaks down to a quarter of the old width limit go by the recurrence as well,
+    re-seeded every 16 (S |D| <= 1 with S = 16) or every 8 points of a lane instead of every 32.
+    At 1e5 grid points over [0, 1]: widths >= 0.0246 seed per window, >= 0.0123 twice, >= 0.00615
+    four times; narrower peaks keep the direct form.  Every class and every mixture of two: within
+    1e-13 sum|term| of the direct kernel, within 1e-12 of the faithful oracle, EQUAL to the mirror;
+    and a walk whose proposals cross the class borders all the time equals the mirror's."""
+    n = 100000
+    s = pb.two_peak(n=n, seed=77)
+    op = s.oracle(orc)
+    os.environ["MHX_FAMILY_WPG"] = wpg
+    try:
+        rec, direct = engines(mhx, s, 4, seed=23)
+        rec.kernel_name(), direct.kernel_name()  # finalise under the pinned family
+    finally:
+        os.environ.pop("MHX_FAMILY_WPG", None)
+    widths = [0.2, 0.03, 0.0247, 0.0245, 0.02, 0.0124, 0.0122, 0.008, 0.00616, 0.00614, 0.004, -0.015, -0.03]
+    rows = []
+    for w1 in widths:
+        for w2 in (0.08, 0.013, 0.007, 0.003):
+            t = s.theta_star.copy()
+            t[4], t[7] = w1, w2
+            rows.append(t)
+    th = np.array(rows)
+    a, b = rec.logpost(th), direct.logpost(th)
+    worst = 0.0
+    for i, t in enumerate(th):
+        scale = op.abs_terms(t)
+        assert abs(a[i] - b[i]) <= 1e-13 * scale, (i, t[4], t[7], a[i], b[i])
+        worst = max(worst, abs(a[i] - b[i]) / scale)
+        assert abs(a[i] - op.logpost(t)) <= REL * scale, (i, t[4], t[7])
+        assert a[i] == op.logpost_mirror(t), (i, t[4], t[7])
+    assert worst < 2e-14  # (measured: 4e-15; the bound above is the stated one)
+    # what the classes are for: a peak between the old limit and a quarter of it now differs
+    # from the direct form (it is advanced by the recurrence), a still narrower one does not
+    t = s.theta_star.copy()
+    t[4] = 0.008
+    assert rec.logpost(t[None])[0] != direct.logpost(t[None])[0]
+    t[4] = 0.004
+    t[7] = 0.003
+    assert rec.logpost(t[None])[0] == direct.logpost(t[None])[0]
+    # a walk from wild proposals (widths all over the classes)
+    th0 = pb.perturbed(s.theta_star, 4, 0.01, seed=5)
+    l0 = np.diag(0.4 * np.abs(s.theta_star))
+    rec.init_chains(th0)
+    rec.adaptive_begin(30000, 10.0, 1, l_matrix=l0)
+    rec.adaptive_advance(40)
+    st = rec.state()
+    for c in range(2):
+        w = orc.Walker(op, th0[c], mirror=True)
+        w.adaptive_begin(30000, 10.0, 1, l_matrix=l0, seed=23, chain_id=c)
+        w.adaptive_advance(40)
+        assert np.array_equal(st["theta"][c], w.last()[0]) and st["logpost"][c] == w.last()[1], c
+    rec.close()
+    direct.close()
