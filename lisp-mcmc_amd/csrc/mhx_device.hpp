@@ -591,6 +591,16 @@ struct PeaksModel {
 #define MHX_SEED_STEPS 32
 #endif
   static constexpr int kSeedSteps = MHX_SEED_STEPS;  // points of a lane from seed to seed
+  // Peaks too narrow for that period (S |D| <= 1 fails for S = kSeedSteps) still go by the
+  // recurrence when half or a quarter of it does: they are re-seeded inside the window as well
+  // (sweep()).  Only for models of at most two peaks, whose tile loops are straight-line variants:
+  // in the run-time-masked loops of bigger models the extra seed sites cost every step 5 %
+  // (config 3, measured) for peaks those problems rarely have.
+#ifdef MHX_ONE_SEED_CLASS  // (build knob for A/B measurements: round 2's single class)
+  static constexpr bool kMultiSeed = false;
+#else
+  static constexpr bool kMultiSeed = NPK <= 2;
+#endif
   struct Rec {
     double g[NPK], r[NPK];
     double b;  // the background's running value (Prep::bgrec)
@@ -844,16 +854,12 @@ struct PeaksModel {
       const bool base = kHasRec && (fast || kHasSkip) && fn.grid_H != 0.0;
       const double ad = fabs(dl);
       const bool ok32 = base && (ad * (double)kSeedSteps <= 1.0);
-      const bool ok16 = base && (ad * (double)(kSeedSteps / 2) <= 1.0);
-      const bool ok8 = base && (ad * (double)(kSeedSteps / 4) <= 1.0);
+      const bool ok16 = kMultiSeed ? base && (ad * (double)(kSeedSteps / 2) <= 1.0) : ok32;
+      const bool ok8 = kMultiSeed ? base && (ad * (double)(kSeedSteps / 4) <= 1.0) : ok32;
       rmask |= ok8 ? (1u << k) : 0u;
       s16 |= (ok8 && !ok32) ? (1u << k) : 0u;
       s8 |= (ok8 && !ok16) ? (1u << k) : 0u;
     }
-#ifdef MHX_ONE_SEED_CLASS  // (build knob for A/B measurements: round 2's single class)
-    rmask &= ~s16;
-    s16 = s8 = 0;
-#endif
     p.rmask = (unsigned)__builtin_amdgcn_readfirstlane((int)rmask);
     p.s16 = (unsigned)__builtin_amdgcn_readfirstlane((int)s16);
     p.s8 = (unsigned)__builtin_amdgcn_readfirstlane((int)s8);

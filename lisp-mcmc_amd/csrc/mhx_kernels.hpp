@@ -588,7 +588,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
                 if ((it * P) % 16 == 0 && gp % kSeedPts == 0) {
                   if ((rm & mask) != 0u) Model::rec_seed(prep, x[0], rm & mask, rs);
                   if constexpr (BGREC) Model::rec_seed_bg(prep, x[0], rs);
-                } else if ((it * P) % (kSeedPts / 4) == 0) {
+                } else if (Model::kMultiSeed && (it * P) % (kSeedPts / 4) == 0) {
                   // narrower peaks, seeded every kSeedPts / 2 or / 4 points of the lane
                   // (PeaksModel::prepare): run-time masks, wave-uniform, rarely non-zero
                   const unsigned ms = (gp % (kSeedPts / 2) == 0 ? seed16 : seed8) & rm & mask;

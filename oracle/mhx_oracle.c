@@ -688,8 +688,9 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
      * or 8 points of a lane; a peak of a shorter class is re-seeded inside the window too */
     const int base = (fast || has_skip) && gH != 0.0;
     const int ok32 = base && (fabs(dl) * (double)MIR_SEED_STEPS <= 1.0);
-    const int ok16 = base && (fabs(dl) * (double)(MIR_SEED_STEPS / 2) <= 1.0);
-    const int ok8 = base && (fabs(dl) * (double)(MIR_SEED_STEPS / 4) <= 1.0);
+    const int multi = npk <= 2; /* PeaksModel::kMultiSeed: models of at most two peaks */
+    const int ok16 = multi ? base && (fabs(dl) * (double)(MIR_SEED_STEPS / 2) <= 1.0) : ok32;
+    const int ok8 = multi ? base && (fabs(dl) * (double)(MIR_SEED_STEPS / 4) <= 1.0) : ok32;
     rec[k] = ok8;
     s16[k] = ok8 && !ok32;
     s8[k] = ok8 && !ok16;
