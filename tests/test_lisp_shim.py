@@ -326,3 +326,41 @@ def test_no_reference_text_in_the_shim():
     assert "mapcon" not in txt
     assert "insufficient depth or improperly structured" not in txt
     assert "insufficient number of datasets" not in txt
+
+
+# ---- what a compiler would say at load time ------------------------------------------------------
+def _shim_sources():
+    return [os.path.join(LISP, f) for f in ("package.lisp", "bindings.lisp", "expr.lisp",
+                                            "models.lisp", "walker.lisp")]
+
+
+def test_no_undefined_function_wrong_arity_or_unbound_variable():
+    """tests/lisp_lint.py walks the shim the way an evaluator would (special forms, the standard
+    binding macros, loop, CFFI's with-foreign-*, the shim's own macros) and reports calls of
+    functions defined nowhere, calls of the shim's own functions (defuns, defcfuns, struct
+    constructors and accessors) with an argument count or keyword their lambda list does not
+    take, and variables bound nowhere - what SBCL would print as warnings when loading a file
+    that has never been loaded."""
+    import lisp_lint
+    problems = lisp_lint.lint(_shim_sources(), own_packages=("mcmc-fitting-amd", "mfit-amd"))
+    assert problems == [], "\n".join(problems)
+
+
+def test_the_walker_does_find_such_mistakes(tmp_path):
+    """... and it is not vacuous: three planted mistakes of those kinds are all reported"""
+    import lisp_lint
+    src = open(os.path.join(LISP, "walker.lisp")).read()
+    bad = (src.replace("(walker-n-params walker)", "(walker-nparams walker)", 1)
+           .replace("(check (%mhx-get-trace e c take pr th n-out))",
+                    "(check (%mhx-get-trace e c take pr th))", 1)
+           .replace("(cffi:mem-ref n-out :int)", "(cffi:mem-ref nout :int)", 1))
+    assert bad != src
+    p = tmp_path / "walker.lisp"
+    p.write_text(bad)
+    problems = lisp_lint.lint(_shim_sources()[:-1] + [str(p)],
+                              own_packages=("mcmc-fitting-amd", "mfit-amd"))
+    text = "\n".join(problems)
+    assert "WALKER-NPARAMS, which is defined nowhere" in text
+    assert "%MHX-GET-TRACE called with 5 argument(s), needs 6" in text
+    assert "variable NOUT is bound nowhere" in text
+    assert len(problems) == 3, text
