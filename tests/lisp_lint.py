@@ -40,6 +40,32 @@ make-symbol string-equal char-equal search mismatch complement constantly princ-
 write write-char write-to-string read-line finish-output fresh-line
 """.upper().split())
 
+# (min, max or None) positional arguments of the standard functions the shim calls most; keyword
+# arguments, where a function takes them, count from `max` on and are not checked
+CL_ARITY = {k.upper(): v for k, v in {
+    "length": (1, 1), "first": (1, 1), "second": (1, 1), "third": (1, 1), "fourth": (1, 1),
+    "car": (1, 1), "cdr": (1, 1), "cadr": (1, 1), "cddr": (1, 1), "rest": (1, 1), "last": (1, 2),
+    "nth": (2, 2), "nthcdr": (2, 2), "elt": (2, 2), "aref": (1, None), "getf": (2, 3),
+    "cons": (2, 2), "list": (0, None), "append": (0, None), "mapcar": (2, None), "mapc": (2, None),
+    "map": (3, None), "every": (2, None), "some": (2, None), "reduce": (2, None),
+    "apply": (2, None), "funcall": (1, None), "format": (2, None), "error": (1, None),
+    "warn": (1, None), "coerce": (2, 2), "floor": (1, 2), "round": (1, 2), "fround": (1, 2),
+    "truncate": (1, 2), "max": (1, None), "min": (1, None), "abs": (1, 1), "sqrt": (1, 1),
+    "exp": (1, 1), "log": (1, 2), "expt": (2, 2), "sin": (1, 1), "cos": (1, 1), "tan": (1, 1),
+    "atan": (1, 2), "tanh": (1, 1), "1+": (1, 1), "1-": (1, 1), "zerop": (1, 1), "not": (1, 1),
+    "null": (1, 1), "consp": (1, 1), "atom": (1, 1), "symbolp": (1, 1), "numberp": (1, 1),
+    "integerp": (1, 1), "floatp": (1, 1), "realp": (1, 1), "rationalp": (1, 1),
+    "stringp": (1, 1), "arrayp": (1, 1), "array-rank": (1, 1), "eq": (2, 2), "eql": (2, 2),
+    "equal": (2, 2), "symbol-name": (1, 1), "intern": (1, 2), "find-package": (1, 1),
+    "gensym": (0, 1), "numerator": (1, 1), "denominator": (1, 1), "char": (2, 2),
+    "string-downcase": (1, None), "string-upcase": (1, None), "prin1-to-string": (1, 1),
+    "princ-to-string": (1, 1), "concatenate": (1, None), "subseq": (2, 3), "nreverse": (1, 1),
+    "reverse": (1, 1), "make-list": (1, None), "make-array": (1, None), "assoc": (2, None),
+    "member": (2, None), "position": (2, None), "remove-if": (2, None), "count": (2, None),
+    "values": (0, None), "identity": (1, 1), "write-string": (1, None), "digit-char-p": (1, 2),
+    "alphanumericp": (1, 1), "char=": (1, None), "string=": (2, None),
+}.items()}
+
 CL_VARIABLES = set("""T NIL PI *PACKAGE* *READ-DEFAULT-FLOAT-FORMAT* *STANDARD-OUTPUT*
 *ERROR-OUTPUT* MOST-POSITIVE-FIXNUM MOST-POSITIVE-DOUBLE-FLOAT""".split())
 
@@ -301,6 +327,9 @@ class Linter:
                 self.check_args(h, ll, args)
             return
         if h in CL_FUNCTIONS:
+            lo_hi = CL_ARITY.get(h)
+            if lo_hi and (len(args) < lo_hi[0] or (lo_hi[1] is not None and len(args) > lo_hi[1])):
+                self.problem("%s called with %d argument(s)" % (h, len(args)))
             return
         if ":" in h and not h.startswith(":"):
             return  # package-qualified: CFFI, ALEXANDRIA, SB-INT ... (not ours: stripped above)

@@ -309,3 +309,66 @@ def test_two_real_gpus_walk_like_two_engines_on_one():
     assert np.array_equal(a0["stats"], a1["stats"]) and a0["refreshes"] == b0["refreshes"] == 3
     assert np.allclose(a0["stats"], b0["stats"], rtol=1e-12, atol=1e-18)
     assert (sa["age"] == sb["age"]).all() and np.isfinite(sa["logpost"]).all()
+
+
+def test_config5_in_its_eight_engine_form_on_one_gpu(tmp_path):
+    """BASELINE config 5 as the node will run it - 524288 chains, 8 engines x 65536, pooled
+    adaptive covariance, one all-reduce of 73 doubles per 200 iterations over 8 communicators from
+    ONE ncclCommInitAll - with the eight engines on the one GPU a test box has and the stand-in
+    librccl as the transport: the partition, the tick at full size (its statistics the sum over
+    all 524288 chains, identical on every engine, its factor the Cholesky factor of the covariance
+    they describe), global chain ids up to 524287 in the Philox counters (chains equal 8-chain
+    engines that own the same ids), every chain moved."""
+    out, calls = run_child("""
+        import bench
+        spec, chains, _, _ = bench.synth_workload("c5")
+        assert chains == 65536 and spec.d == 8
+        N = 8 * chains
+        g = mhx.Group(N, spec.d, spec.K, devices=[0] * 8, seed=21, adapt_mode=mhx.capi.ADAPT_POOLED)
+        assert g.ranges == [(i * chains, chains) for i in range(8)]
+        spec.apply(g)
+        rng = np.random.Generator(np.random.Philox(key=99))
+        th0 = spec.theta_star[None, :] * (1.0 + 0.01 * rng.standard_normal((N, spec.d)))
+        l0 = np.diag(0.01 * np.abs(spec.theta_star))
+        g.init_chains(th0)
+        g.adaptive_begin(30000, 10.0, 1, l_matrix=l0)
+        n_it = 212
+        assert g.adaptive_advance(n_it) == N
+        st = g.state()
+        assert (st["age"] == n_it + 1).all() and g.counters()[0] == N * n_it
+        assert np.isfinite(st["logpost"]).all()
+        pools = [e.pooled() for e in g.engines]
+        d = spec.d
+        for p in pools:
+            assert p["refreshes"] == 1 and p["valid"]
+            assert np.array_equal(p["stats"], pools[0]["stats"]) and np.array_equal(p["L"], pools[0]["L"])
+        n = pools[0]["stats"][0]
+        assert n == np.floor(n) and n > N
+        mean = pools[0]["stats"][1:1 + d] / n
+        cov = pools[0]["stats"][1 + d:].reshape(d, d) / n - np.outer(mean, mean)
+        assert np.allclose(pools[0]["L"], (2.38 ** 2 / d) * np.linalg.cholesky(cov), rtol=1e-9, atol=1e-18)
+        # one engine's share on its own sees one eighth of the displacements, give or take
+        one = spec.engine(mhx, chains, seed=21, chain_offset=3 * chains, adapt_mode=mhx.capi.ADAPT_POOLED)
+        one.init_chains(th0[3 * chains:4 * chains])
+        one.adaptive_begin(30000, 10.0, 1, l_matrix=l0)
+        one.adaptive_advance(200)
+        assert 0.11 < one.pooled()["stats"][0] / n < 0.14
+        one.close()
+        for lo in (0, 3 * chains + 40000, N - 8):
+            small = spec.engine(mhx, 8, seed=21, chain_offset=lo, adapt_mode=mhx.capi.ADAPT_POOLED)
+            small.init_chains(th0[lo:lo + 8])
+            small.adaptive_begin(30000, 10.0, 1, l_matrix=l0)
+            small.adaptive_advance(n_it)
+            ss = small.state()
+            assert np.array_equal(st["theta"][lo:lo + 8], ss["theta"]), lo
+            assert np.array_equal(st["logpost"][lo:lo + 8], ss["logpost"]), lo
+            small.close()
+        g.close()
+        print("ok")
+    """, tmp_path)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
+    assert calls[0] == "CommInitAll ndev=8 devices=0,0,0,0,0,0,0,0"
+    i = calls.index("GroupStart depth=1")
+    assert [c.split()[1] for c in calls[i + 1:i + 9]] == ["rank=%d" % r for r in range(8)]
+    assert calls[i + 9] == "GroupEnd depth=0 pending=8" and calls[i + 10] == "flush clique_of=8 count=73 rc=0"
+    assert sum(c.startswith("CommDestroy") for c in calls) == 8
