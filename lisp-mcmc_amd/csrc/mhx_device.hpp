@@ -1192,9 +1192,29 @@ struct PVoigt2Model {
     asm volatile("" : "+v"(a));
     asm volatile("" : "+v"(b));
     p.g1c = a; p.g2c = b;
+    // likewise the additive constants of u1, u2 and of the background: an fma may read ONE scalar
+    // operand, and left in scalar registers these three were copied into a vector register in
+    // every iteration of the tile loop (3 v_mov_b64 per 2 points: 1.5 of 55 instructions per point)
+    {
+      double c1v = p.c1, c2v = p.c2p, b0v = p.b0;
+      asm volatile("" : "+v"(c1v));
+      asm volatile("" : "+v"(c2v));
+      asm volatile("" : "+v"(b0v));
+      p.c1 = c1v; p.c2p = c2v; p.b0 = b0v;
+    }
     const double e1 = fabs(__builtin_fma(fn.xmin, p.g1w, p.g1c)), e2 = fabs(__builtin_fma(fn.xmax, p.g1w, p.g1c));
     const double e3 = fabs(__builtin_fma(fn.xmin, p.g2w, p.g2c)), e4 = fabs(__builtin_fma(fn.xmax, p.g2w, p.g2c));
     p.fast = (e1 < kFastT) && (e2 < kFastT) && (e3 < kFastT) && (e4 < kFastT);  // NaN fails
+    // ... and the fast path forms both Lorentzians from ONE reciprocal, 1 / ((1 + u1^2)(1 + u2^2))
+    // (finish_fast): the product must not overflow anywhere in the data range.  |t| < kFastT
+    // already bounds |u| by 2890 / sqrt(log2 e), so this holds whenever the line above does; it
+    // is spelt out because it is what finish_fast relies on.
+    {
+      const double g = kSqrtLog2e;
+      const double d1 = __builtin_fma(e1 > e2 ? e1 : e2, (e1 > e2 ? e1 : e2) / (g * g), 1.0);
+      const double d2 = __builtin_fma(e3 > e4 ? e3 : e4, (e3 > e4 ? e3 : e4) / (g * g), 1.0);
+      p.fast = p.fast && (d1 * d2 < 1e300);
+    }
     p.K.pin();
     return p;
   }
@@ -1208,6 +1228,19 @@ struct PVoigt2Model {
     const double bg = __builtin_fma(p.c2, x * x, __builtin_fma(p.b1, x, p.b0));
     return __builtin_fma(p.A, __builtin_fma(p.rho, pv2, pv1), bg);
   }
+  // ... on the fast path with ONE reciprocal for the two Lorentzians: y = 1 / (d1 d2),
+  // 1 / d1 = y d2, 1 / d2 = y d1 - 8 instructions where two reciprocals take 10 (Prep::fast
+  // guarantees that d1 d2 stays finite; each quotient within 2.5 ulp instead of 1)
+  static __device__ __forceinline__ double finish_fast(const Prep& p, double x, double u1,
+                                                       double u2, double g1, double g2) {
+    const double d1 = __builtin_fma(u1, u1, 1.0), d2 = __builtin_fma(u2, u2, 1.0);
+    const double y = frcp(d1 * d2);
+    const double l1 = y * d2, l2 = y * d1;
+    const double pv1 = __builtin_fma(p.eta1, l1, p.om1 * g1);
+    const double pv2 = __builtin_fma(p.eta2, l2, p.om2 * g2);
+    const double bg = __builtin_fma(p.c2, x * x, __builtin_fma(p.b1, x, p.b0));
+    return __builtin_fma(p.A, __builtin_fma(p.rho, pv2, pv1), bg);
+  }
   template <bool FAST>
   static __device__ __forceinline__ double eval(const Prep& p, double x) {
     const double u1 = __builtin_fma(x, p.iw1, p.c1), u2 = __builtin_fma(x, p.iw2, p.c2p);
@@ -1215,6 +1248,7 @@ struct PVoigt2Model {
     if (FAST) {
       g1 = mexp2_negsq(__builtin_fma(x, p.g1w, p.g1c), p.K);
       g2 = mexp2_negsq(__builtin_fma(x, p.g2w, p.g2c), p.K);
+      return finish_fast(p, x, u1, u2, g1, g2);
     } else {
       g1 = mexp2_negsq_safe(u1 * kSqrtLog2e);
       g2 = mexp2_negsq_safe(u2 * kSqrtLog2e);
@@ -1240,7 +1274,7 @@ struct PVoigt2Model {
 #pragma unroll
       for (int i = 0; i < P; ++i) {
         const double u1 = __builtin_fma(x[i], p.iw1, p.c1), u2 = __builtin_fma(x[i], p.iw2, p.c2p);
-        f[i] = finish(p, x[i], u1, u2, v[2 * i], v[2 * i + 1]);
+        f[i] = finish_fast(p, x[i], u1, u2, v[2 * i], v[2 * i + 1]);
       }
     } else {
 #pragma unroll
