@@ -1175,6 +1175,7 @@ struct PVoigt2Model {
   struct Prep {
     double A, b0, b1, c1, iw1, eta1, om1, c2p, iw2, eta2, om2, rho, c2;
     double g1c, g1w, g2c, g2w;  // the same lines scaled by g (VGPR-pinned constants of the fma)
+    double k1, k2, k3, k4;      // A eta1, A (1 - eta1), A rho eta2, A rho (1 - eta2): finish_fast
     Exp2K K;
     bool fast;
   };
@@ -1187,6 +1188,8 @@ struct PVoigt2Model {
     p.iw2 = uniform_f64(iw2); p.c2p = uniform_f64(-pf(6) * iw2); p.eta2 = uniform_f64(pf(8));
     p.om1 = uniform_f64(1.0 - pf(5)); p.om2 = uniform_f64(1.0 - pf(8));
     p.rho = uniform_f64(pf(9)); p.c2 = uniform_f64(pf(10));
+    p.k1 = uniform_f64(p.A * p.eta1); p.k2 = uniform_f64(p.A * p.om1);
+    p.k3 = uniform_f64((p.A * p.rho) * p.eta2); p.k4 = uniform_f64((p.A * p.rho) * p.om2);
     p.g1w = uniform_f64(p.iw1 * kSqrtLog2e); p.g2w = uniform_f64(p.iw2 * kSqrtLog2e);
     double a = p.c1 * kSqrtLog2e, b = p.c2p * kSqrtLog2e;
     asm volatile("" : "+v"(a));
@@ -1230,16 +1233,20 @@ struct PVoigt2Model {
   }
   // ... on the fast path with ONE reciprocal for the two Lorentzians: y = 1 / (d1 d2),
   // 1 / d1 = y d2, 1 / d2 = y d1 - 8 instructions where two reciprocals take 10 (Prep::fast
-  // guarantees that d1 d2 stays finite; each quotient within 2.5 ulp instead of 1)
+  // guarantees that d1 d2 stays finite; each quotient within 2.5 ulp instead of 1).  Within the
+  // stated 1e-12 sum |term| of the reference's nested form (tests/test_gpu_fullsize.py, config 4).
   static __device__ __forceinline__ double finish_fast(const Prep& p, double x, double u1,
                                                        double u2, double g1, double g2) {
     const double d1 = __builtin_fma(u1, u1, 1.0), d2 = __builtin_fma(u2, u2, 1.0);
     const double y = frcp(d1 * d2);
     const double l1 = y * d2, l2 = y * d1;
-    const double pv1 = __builtin_fma(p.eta1, l1, p.om1 * g1);
-    const double pv2 = __builtin_fma(p.eta2, l2, p.om2 * g2);
-    const double bg = __builtin_fma(p.c2, x * x, __builtin_fma(p.b1, x, p.b0));
-    return __builtin_fma(p.A, __builtin_fma(p.rho, pv2, pv1), bg);
+    // A (pv1 + rho pv2) + bg with the four products of its constants formed once per step:
+    // four fmas on top of the background where the nested form takes six operations
+    double f = __builtin_fma(p.c2, x * x, __builtin_fma(p.b1, x, p.b0));
+    f = __builtin_fma(p.k1, l1, f);
+    f = __builtin_fma(p.k2, g1, f);
+    f = __builtin_fma(p.k3, l2, f);
+    return __builtin_fma(p.k4, g2, f);
   }
   template <bool FAST>
   static __device__ __forceinline__ double eval(const Prep& p, double x) {
