@@ -538,23 +538,45 @@ constexpr double kSqrtLog2e = 1.2011224087864497594;   // sqrt(log2(e))
 template <int NBG, int NPK, bool LORENTZ>
 struct PeaksModel {
   static constexpr bool kHasFast = !LORENTZ;
+  static constexpr bool kSeedInLds = !LORENTZ && NPK > 2;  // (Prep::sc; needs prepare(pf, fn, scratch))
+  static constexpr int kScratchDoubles = 4 * NPK;
   struct Prep {
     double bg[NBG > 0 ? NBG : 1];
-    double A[NPK], mu[NPK], iw[NPK];
-    double cv[NPK];  // mu[] once more, pinned in VGPRs: t = fma(x, iw, c) may read only ONE
+    double A[NPK];
+    double mu[kSeedInLds ? 1 : NPK], iw[kSeedInLds ? 1 : NPK];
+    double cv[kSeedInLds ? 1 : NPK];  // mu[] once more, pinned in VGPRs: t = fma(x, iw, c) may read only ONE
                      // scalar operand (constant bus), so c would be re-copied for every point
     Exp2K K;         // the constants of the 2^f polynomial, pinned likewise
     bool fast;  // |t| < kFastT over the whole x range for every peak (uniform)
     bool skip;  // tile-level skipping by the relative rule allowed this step (see tile_mask)
     bool afin;  // every amplitude is finite (the exact-zero rule of tile_mask)
-    int thr[NPK];  // -(binary exponent of A_k) - 56
     // uniform-grid recurrence (below): per peak -2 D, -D^2 and 2^(-2 D^2), D = the step of t from
     // one point of a lane to its next (64 grid points on); rec: usable this step
-    double rm2d[NPK], rnd2[NPK], rq[NPK];
+    double rm2d[kSeedInLds ? 1 : NPK], rnd2[kSeedInLds ? 1 : NPK], rq[NPK];
     unsigned rmask;  // bit k: peak k goes by the recurrence this step
     // narrower peaks go by it too, re-seeded more often: bit k of s16 - also every kSeedSteps / 2
     // points of the lane; of s8 - every kSeedSteps / 4 (a peak in s8 is in s16 as well)
     unsigned s16, s8;
+    // kSeedInLds (more than two peaks): what only the seeds, a direct-form block and tile_mask
+    // read - c = -mu iw, iw, -2 D, -D^2 of every peak - waits in the wave's LDS scratch
+    // (sc[4 k .. 4 k + 3]) instead of 8 scalar registers per peak.  With five peaks those were 40
+    // of the ~100 scalar registers a wave has; the compiler kept them and spilled A and q - which
+    // every POINT needs - to vector lanes, reloading them (4 v_readlane per peak and 4 points) in
+    // the hot blocks, and materialised the constants of the Poisson term's log in vector
+    // registers per point: a quarter of config 3's instructions.
+    lds_cdptr_t sc;
+    __device__ __forceinline__ double c_of(int k) const {
+      if constexpr (kSeedInLds) return sc[4 * k]; else return mu[k];
+    }
+    __device__ __forceinline__ double iw_of(int k) const {
+      if constexpr (kSeedInLds) return sc[4 * k + 1]; else return iw[k];
+    }
+    __device__ __forceinline__ double rm2d_of(int k) const {
+      if constexpr (kSeedInLds) return sc[4 * k + 2]; else return rm2d[k];
+    }
+    __device__ __forceinline__ double rnd2_of(int k) const {
+      if constexpr (kSeedInLds) return sc[4 * k + 3]; else return rnd2[k];
+    }
     // ... and when EVERY peak does, so does a constant or linear background (b(x + 64 h) =
     // b(x) + 64 h b1, re-seeded with the peaks): such a step never reads x beyond the seeds, which
     // takes a third off the LDS traffic of the sweep.  Decided per step, not per tile.
@@ -642,11 +664,11 @@ struct PeaksModel {
         if (kHasSkip && !((mask >> k) & 1u)) continue;  // wave-uniform
         double t[2], v[2];
         const bool on[2] = {true, true};
-        t[0] = __builtin_fma(x0, p.iw[k], p.mu[k]);
+        t[0] = __builtin_fma(x0, p.iw_of(k), p.c_of(k));
         // (forming -2 D and -D^2 here from D = 64 h iw instead of keeping them per peak takes the
         // kernel's scratch from 224 to 188 B per lane and config 3 from 7.70e5 to 7.31e5
         // chain-steps/s: the reloads at the seeds are cheaper than the arithmetic - measured)
-        t[1] = __builtin_fma(p.rm2d[k], t[0], p.rnd2[k]);
+        t[1] = __builtin_fma(p.rm2d_of(k), t[0], p.rnd2_of(k));
         mexp2_negsq_batch<2, true>(t, on, p.K, v);
         rs.g[k] = v[0];
         rs.r[k] = v[1];
@@ -709,13 +731,14 @@ struct PeaksModel {
             rs.r[k] = rs.r[k] * p.rq[k];
           }
         } else {
-          double t[P], v[P], ck = p.mu[k];
+          double t[P], v[P], ck = p.c_of(k);
           asm volatile("" : "+v"(ck));
           bool on[P];
+          const double iwk = p.iw_of(k);
 #pragma unroll
           for (int i = 0; i < P; ++i) {
             on[i] = true;
-            t[i] = fma_svv(x[i], p.iw[k], ck);
+            t[i] = kSeedInLds ? __builtin_fma(x[i], iwk, ck) : fma_svv(x[i], iwk, ck);
           }
           mexp2_negsq_batch<P>(t, on, p.K, v);
 #pragma unroll
@@ -777,8 +800,11 @@ struct PeaksModel {
     bool guard = false;
 #pragma unroll
     for (int k = 0; k < NPK; ++k) {
-      const double tl = __builtin_fma(xlo, p.iw[k], p.cv[k]);
-      const double th = __builtin_fma(xhi, p.iw[k], p.cv[k]);
+      const double iwk = p.iw_of(k), ck = kSeedInLds ? p.c_of(k) : p.cv[k];
+      const double tl = __builtin_fma(xlo, iwk, ck);
+      const double th = __builtin_fma(xhi, iwk, ck);
+      // -(binary exponent of A_k) - 56, formed here (once per 64 windows) rather than kept
+      const int thr_k = -__builtin_amdgcn_frexp_exp(p.A[k]) - 56;
       const bool same_side = (tl > 0.0 && th > 0.0) || (tl < 0.0 && th < 0.0);
       const double al = fabs(tl), ah = fabs(th);
       const double tmin = al < ah ? al : ah;
@@ -789,7 +815,7 @@ struct PeaksModel {
       const int kmin = (int)__double_as_longlong(kd) >> 8;  // (meaningful when `in`)
       const int ef = __builtin_amdgcn_frexp_exp(lbr);       // lbr in [2^(ef-1), 2^ef)
       const bool noop =
-          far || ((lbr > 0.0) && in && same_side && (kmin <= ef + p.thr[k]));
+          far || ((lbr > 0.0) && in && same_side && (kmin <= ef + thr_k));
       m |= noop ? 0u : (1u << k);
       // an evaluated peak moves f by less than 2^(ea + kmin + 1) (by less than 2^(ea + 1) when
       // its centre lies inside the window): a non-negative addend to a positive f leaves bg's
@@ -797,7 +823,7 @@ struct PeaksModel {
       if (!noop && !(mono && p.A[k] >= 0.0)) {
         mono = false;
         const int km = (same_side && in) ? kmin : 0;
-        const double left = lbr - ldexp(1.0, km - p.thr[k] - 55);
+        const double left = lbr - ldexp(1.0, km - thr_k - 55);
         lbr = left > 0.0 ? left : 0.0;  // (NaN: 0)
       }
     }
@@ -805,9 +831,11 @@ struct PeaksModel {
     // broadcasts the window's word with readlane, so the tests in eval() are scalar branches
     return m | (guard ? kGuardBit : 0u);
   }
+  // scratch: kScratchDoubles doubles of the wave's own LDS (kSeedInLds; ignored otherwise)
   template <class PF>
-  static __device__ __forceinline__ Prep prepare(PF pf, const FnDesc& fn) {
+  static __device__ __forceinline__ Prep prepare(PF pf, const FnDesc& fn, double* scratch = nullptr) {
     Prep p;
+    p.sc = (lds_cdptr_t)scratch;
     bool fast = true;
     bool skip = fn.tile_skip != 0;
     bool afin = true;
@@ -824,18 +852,27 @@ struct PeaksModel {
       const double mu = pf(NBG + 3 * k + 1);
       // Gaussian: exp(-((x-mu)/w)^2) = 2^(-t^2) with t = x*iw' - mu*iw', iw' = sqrt(log2 e)/w
       const double iw = LORENTZ ? 1.0 / pf(NBG + 3 * k + 2) : kSqrtLog2e / pf(NBG + 3 * k + 2);
-      p.iw[k] = uniform_f64(iw);
-      p.mu[k] = uniform_f64(-mu * iw);  // additive constant of the fma below
-      double cvk = p.mu[k];
-      if (NPK <= 2) asm volatile("" : "+v"(cvk));  // (more peaks: eval_n moves it per block)
-      p.cv[k] = cvk;
+      const double iwu = uniform_f64(iw);
+      const double cu = uniform_f64(-mu * iw);  // additive constant of the fma below
+      if constexpr (kSeedInLds) {
+        if (lane_id() == 0) {
+          scratch[4 * k] = cu;
+          scratch[4 * k + 1] = iwu;
+        }
+        p.mu[0] = p.iw[0] = p.cv[0] = 0.0;
+      } else {
+        p.iw[k] = iwu;
+        p.mu[k] = cu;
+        double cvk = cu;
+        if (NPK <= 2) asm volatile("" : "+v"(cvk));  // (more peaks: eval_n moves it per block)
+        p.cv[k] = cvk;
+      }
       // t is linear in x: its extremes sit at the ends of the data range (NaN fails the test)
-      const double ta = fabs(__builtin_fma(fn.xmin, p.iw[k], p.mu[k]));
-      const double tb = fabs(__builtin_fma(fn.xmax, p.iw[k], p.mu[k]));
+      const double ta = fabs(__builtin_fma(fn.xmin, iwu, cu));
+      const double tb = fabs(__builtin_fma(fn.xmax, iwu, cu));
       fast = fast && (ta < kFastT) && (tb < kFastT);
       // |A_k| < 2^ea; an infinite or NaN amplitude switches skipping off
       afin = afin && finite_f64(p.A[k]);
-      p.thr[k] = __builtin_amdgcn_readfirstlane(-__builtin_amdgcn_frexp_exp(p.A[k]) - 56);
     }
     p.fast = fast;
     // (with kHasSkip the fast / guarded choice is made per window, tile_mask; without it per step)
@@ -845,10 +882,21 @@ struct PeaksModel {
     unsigned rmask = 0, s16 = 0, s8 = 0;
 #pragma unroll
     for (int k = 0; k < NPK; ++k) {
-      const double dl = fn.grid_H * p.iw[k];  // D_k
-      p.rm2d[k] = uniform_f64(-2.0 * dl);
-      p.rnd2[k] = uniform_f64(-(dl * dl));
-      p.rq[k] = uniform_f64(mexp2(2.0 * p.rnd2[k]));
+      // (the same iw as above: recomputed rather than kept across the loops)
+      const double iwk = uniform_f64(LORENTZ ? 1.0 / pf(NBG + 3 * k + 2) : kSqrtLog2e / pf(NBG + 3 * k + 2));
+      const double dl = fn.grid_H * iwk;  // D_k
+      const double rm2d_k = uniform_f64(-2.0 * dl), rnd2_k = uniform_f64(-(dl * dl));
+      if constexpr (kSeedInLds) {
+        if (lane_id() == 0) {
+          scratch[4 * k + 2] = rm2d_k;
+          scratch[4 * k + 3] = rnd2_k;
+        }
+        p.rm2d[0] = p.rnd2[0] = 0.0;
+      } else {
+        p.rm2d[k] = rm2d_k;
+        p.rnd2[k] = rnd2_k;
+      }
+      p.rq[k] = uniform_f64(mexp2(2.0 * rnd2_k));
       // three classes by the peak's width in grid points: S |D| <= 1 for the seeding period S the
       // peak gets (kSeedSteps, half of it, a quarter of it); NaN fails all three
       const bool base = kHasRec && (fast || kHasSkip) && fn.grid_H != 0.0;
@@ -870,6 +918,7 @@ struct PeaksModel {
     p.bgrec = false;
 #endif
     p.bgH = NBG == 2 ? uniform_f64(p.bg[1] * fn.grid_H) : 0.0;
+    if constexpr (kSeedInLds) __builtin_amdgcn_wave_barrier();  // (the wave's own LDS writes above)
     return p;
   }
   static __device__ __forceinline__ bool fast_ok(const Prep& p) { return p.fast; }
@@ -885,7 +934,8 @@ struct PeaksModel {
 #pragma unroll
     for (int k = 0; k < NPK; ++k) {
       if (FAST && kHasSkip && !((mask >> k) & 1u)) continue;
-      const double t = __builtin_fma(x, p.iw[k], p.cv[k]);
+      const double t = kSeedInLds ? __builtin_fma(x, p.iw_of(k), p.c_of(k))
+                                  : __builtin_fma(x, p.iw[k], p.cv[k]);
       if (LORENTZ)
         f = __builtin_fma(p.A[k], frcp(__builtin_fma(t, t, 1.0)), f);
       else
@@ -935,13 +985,14 @@ struct PeaksModel {
         // one peak (a basic block of its own under a run-time mask): its P points as one batch.
         // The additive constant moves to a vector register HERE (one v_mov per block and P
         // points) rather than being pinned in one for the whole sweep: NPK register pairs less
-        double t[P], v[P], ck = p.mu[k];
+        double t[P], v[P], ck = p.c_of(k);
         asm volatile("" : "+v"(ck));
         bool on[P];
+        const double iwk = p.iw_of(k);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
           on[i] = true;
-          t[i] = fma_svv(x[i], p.iw[k], ck);
+          t[i] = kSeedInLds ? __builtin_fma(x[i], iwk, ck) : fma_svv(x[i], iwk, ck);
         }
         mexp2_negsq_batch<P>(t, on, p.K, v);
 #pragma unroll
@@ -949,7 +1000,8 @@ struct PeaksModel {
       } else {
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-          const double t = __builtin_fma(x[i], p.iw[k], p.cv[k]);
+          const double t = kSeedInLds ? __builtin_fma(x[i], p.iw_of(k), p.c_of(k))
+                                      : __builtin_fma(x[i], p.iw[k], p.cv[k]);
           if (LORENTZ)
             f[i] = __builtin_fma(p.A[k], frcp(__builtin_fma(t, t, 1.0)), f[i]);
           else
@@ -1058,6 +1110,19 @@ template <class M, bool = model_has_rec<M>::value>
 struct model_seed_steps { static constexpr int value = 16; };
 template <class M>
 struct model_seed_steps<M, true> { static constexpr int value = M::kSeedSteps; };
+// models that keep part of their per-step constants in the wave's LDS scratch
+// (PeaksModel::kSeedInLds): prepare(pf, fn, scratch)
+template <class M, class = void>
+struct model_wants_scratch { static constexpr bool value = false; };
+template <class M>
+struct model_wants_scratch<M, decltype((void)M::kSeedInLds, void())> {
+  static constexpr bool value = M::kSeedInLds;
+};
+template <class M, class PF>
+__device__ __forceinline__ typename M::Prep model_prepare(PF pf, const FnDesc& fn, double* scratch) {
+  if constexpr (model_wants_scratch<M>::value) return M::prepare(pf, fn, scratch);
+  else return M::prepare(pf, fn);
+}
 template <class M, class = void>
 struct model_has_eval_n { static constexpr bool value = false; };
 template <class M>

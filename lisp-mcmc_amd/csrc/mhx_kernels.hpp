@@ -836,8 +836,8 @@ struct FixedSpec {
   // partial likelihood sum over points [p0, p1) (split mode; no barriers, one wave)
   template <class PF>
   static __device__ __forceinline__ double loglik_part(const FnDesc& f, PF pf, int64_t p0,
-                                                       int64_t p1) {
-    typename Model::Prep prep = Model::prepare(pf, f);
+                                                       int64_t p1, double* scratch) {
+    typename Model::Prep prep = model_prepare<Model>(pf, f, scratch);
     if constexpr (model_has_fast<Model>::value) {
       if (Model::fast_ok(prep)) {
         if constexpr (model_has_rec<Model>::value &&
@@ -856,8 +856,8 @@ struct FixedSpec {
   }
   template <class PF>
   static __device__ __forceinline__ double loglik(const FnDesc& f, PF pf, bool active,
-                                                  GroupLds& lds, double*) {
-    typename Model::Prep prep = Model::prepare(pf, f);
+                                                  GroupLds& lds, double* scratch) {
+    typename Model::Prep prep = model_prepare<Model>(pf, f, scratch);
     bool fast = false;
     unsigned rmask = 0u;
     if constexpr (model_has_fast<Model>::value)
@@ -881,7 +881,7 @@ struct FixedSpec {
 struct GenericSpec {
   static constexpr bool kSplit = false;  // models whose parameters live in LDS: batch kernels only
   template <class PF>
-  static __device__ __forceinline__ double loglik_part(const FnDesc&, PF, int64_t, int64_t) {
+  static __device__ __forceinline__ double loglik_part(const FnDesc&, PF, int64_t, int64_t, double*) {
     return 0.0;
   }
   static __device__ __forceinline__ double logprior(const FnDesc&, const double*, double bt) {
@@ -889,7 +889,7 @@ struct GenericSpec {
   }
   template <class Model, class PF>
   static __device__ __forceinline__ double by_lik(const FnDesc& f, PF pf, bool active, GroupLds& lds) {
-    typename Model::Prep prep = Model::prepare(pf, f);
+    typename Model::Prep prep = model_prepare<Model>(pf, f, lds.prm[wave_in_group()]);
     switch (f.lik) {
       case MHX_LIK_NORMAL:
         return finish_lik<MHX_LIK_NORMAL>(f, sweep<Model, MHX_LIK_NORMAL>(f, prep, active, lds));
@@ -904,7 +904,7 @@ struct GenericSpec {
   template <class Model, int LIK, class PF>
   static __device__ __forceinline__ double one_lik(const FnDesc& f, PF pf, bool active,
                                                    GroupLds& lds) {
-    typename Model::Prep prep = Model::prepare(pf, f);
+    typename Model::Prep prep = model_prepare<Model>(pf, f, lds.prm[wave_in_group()]);
     return finish_lik<LIK>(f, sweep<Model, LIK>(f, prep, active, lds));
   }
   template <class Model, class PF>
@@ -1805,6 +1805,7 @@ template <class Spec>
 __device__ __forceinline__ void k_split_sweep_body(const ProblemDesc* __restrict__ Pp,
                                                    ChainState S) {
   __shared__ double sprop[kWavesPerGroup][MHX_MAX_PARAMS];
+  __shared__ double sscr[kWavesPerGroup][MHX_MAX_FN_PARAMS + 4];  // (model_wants_scratch)
   const ProblemDesc& P = *Pp;
   const int w = wave_in_group(), l = lane_id(), d = P.d;
   const int64_t c = blockIdx.y;
@@ -1824,7 +1825,7 @@ __device__ __forceinline__ void k_split_sweep_body(const ProblemDesc* __restrict
     const int64_t per = (pairs + S.split_slots - 1) / S.split_slots;
     const int64_t b0 = (int64_t)slot * per, b1 = b0 + per < pairs ? b0 + per : pairs;
     double v = 0.0;
-    if (b0 < b1) v = Spec::loglik_part(f, pf, b0 * 2 * kWave, b1 * 2 * kWave);
+    if (b0 < b1) v = Spec::loglik_part(f, pf, b0 * 2 * kWave, b1 * 2 * kWave, sscr[w]);
     if (l == 0) S.split_part[(c * P.K + k) * S.split_slots + slot] = v;
   }
 }

@@ -246,15 +246,15 @@ static std::string generate(const std::vector<UserExpr>& models,
        "  static constexpr bool kSplit = true;\n"
        "  template <class PF>\n"
        "  static __device__ __forceinline__ double loglik_part(const FnDesc& f, PF pf, int64_t p0,\n"
-       "                                                       int64_t p1) {\n"
+       "                                                       int64_t p1, double* scratch) {\n"
        "    switch (f.user_slot) {\n";
   for (size_t m = 0; m < models.size(); ++m) {
     const int lik = models[m].lik;
     if (with_split && lik >= 0 && lik <= 3)
       s << "      case " << m << ": return FixedSpec<UserModel" << m << ", " << kLikName[lik]
-        << ">::loglik_part(f, pf, p0, p1);\n";
+        << ">::loglik_part(f, pf, p0, p1, scratch);\n";
   }
-  s << "      default: return 0.0;\n    }\n  }\n"
+  s << "      default: (void)scratch; return 0.0;\n    }\n  }\n"
        "  static __device__ __forceinline__ double logprior(const FnDesc& f, const double* th,\n"
        "                                                    double bounds_total) {\n"
        "    switch (f.prior_slot) {\n";
