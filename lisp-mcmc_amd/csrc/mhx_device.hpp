@@ -66,6 +66,33 @@ __device__ __forceinline__ lds_cdptr_t lds_logtab() {
 __device__ __forceinline__ lds_cd2ptr_t lds_exp2tab() {
   return (lds_cd2ptr_t)reinterpret_cast<LdsHead*>(mhx_lds_raw)->exp2tab;
 }
+// The tables are READ at absolute LDS addresses: no kernel that reads them has static LDS (the
+// host checks it where it configures the kernels: mhx_launch.inc, mhx_rtc.cpp), so the dynamic
+// LDS - and with it LdsHead - starts at address 0.  Through mhx_lds_raw the compiler forms
+// `index * 16 + <symbol>` and, the symbol being resolved to 0 only after instruction selection,
+// leaves a `v_add_u32 v, 0, v` (log) or spends the add of a v_lshl_add_u32 (exp) on it in
+// every call; with the byte address formed as an integer the table's offset folds into the DS
+// instruction's offset field.
+constexpr unsigned kLdsLogTab = 0u;       // __builtin_offsetof(LdsHead, logtab)
+constexpr unsigned kLdsExp2Tab = 2048u;   // __builtin_offsetof(LdsHead, exp2tab)
+static_assert(__builtin_offsetof(LdsHead, logtab) == kLdsLogTab &&
+              __builtin_offsetof(LdsHead, exp2tab) == kLdsExp2Tab, "LdsHead moved");
+// {Th_j, rho_j} of kExp2Tab for j = the low byte of `lo`: the byte select and the scaling by the
+// entry size in ONE instruction (an SDWA operand selects byte 0 of the register), where
+// `(lo & 255) << 4` is two
+__device__ __forceinline__ mhx_double2 exp2tab_entry(int lo) {
+  unsigned a;
+  asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD "
+      "src1_sel:BYTE_0"
+      : "=v"(a)
+      : "v"(lo));
+  return ((lds_cd2ptr_t)(__UINTPTR_TYPE__)a)[kLdsExp2Tab / 16];
+}
+// {1/c_i, log c_i} of kLogTab for i = bits 13..19 of `th`
+__device__ __forceinline__ mhx_double2 logtab_entry(unsigned th) {
+  const unsigned a = (th >> 9) & 0x7F0u;
+  return ((lds_cd2ptr_t)(__UINTPTR_TYPE__)a)[kLdsLogTab / 16];
+}
 
 // ------------------------------------------------------------------------------------------
 // wave helpers
@@ -296,7 +323,7 @@ __device__ __forceinline__ void mexp2_negsq_head(double t, const Exp2K& K, Exp2H
   const double kf = kd - K.magic;
   h.r = __builtin_fma(-t, t, -kf);
   h.lo = (int)__double_as_longlong(kd);
-  h.e = lds_exp2tab()[h.lo & 255];
+  h.e = exp2tab_entry(h.lo);
 }
 // the same reduction for an argument s given as it is (|s| < 2^22): 2^s = tail(head)
 __device__ __forceinline__ void mexp2_head(double s, const Exp2K& K, Exp2Head& h) {
@@ -304,7 +331,7 @@ __device__ __forceinline__ void mexp2_head(double s, const Exp2K& K, Exp2Head& h
   const double kf = kd - K.magic;
   h.r = s - kf;  // exact: both multiples of ulp(s), difference at most 2^-9
   h.lo = (int)__double_as_longlong(kd);
-  h.e = lds_exp2tab()[h.lo & 255];
+  h.e = exp2tab_entry(h.lo);
 }
 __device__ __forceinline__ double mexp2_negsq_tail(const Exp2Head& h, const Exp2K& K) {
   double a = __builtin_fma(h.r, K.q3, K.q[0]);
@@ -441,11 +468,12 @@ __device__ __forceinline__ double tlog(double x, lds_cdptr_t tab, double A3 = kT
   const unsigned long long b = (unsigned long long)__double_as_longlong(x);
   const unsigned hx = (unsigned)(b >> 32), lx = (unsigned)b;
   const unsigned th = hx - 0x3FE60000u;  // high word of bits(x) - OFF (OFF's low word is 0)
-  const int i = (int)((th >> 13) & 127u);
+  const mhx_double2 ic = logtab_entry(th);  // entry (th >> 13) & 127
   const int k = (int)th >> 20;
   const unsigned zh = hx - (th & 0xFFF00000u);
   const double z = __longlong_as_double((long long)(((unsigned long long)zh << 32) | lx));
-  const double invc = tab[2 * i], logc = tab[2 * i + 1];
+  const double invc = ic.x, logc = ic.y;
+  (void)tab;
   const double r = __builtin_fma(z, invc, -1.0);
   const double kd = (double)k;
   const double w = __builtin_fma(kd, Ln2hi, logc);  // exact

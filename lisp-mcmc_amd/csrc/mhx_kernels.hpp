@@ -40,7 +40,16 @@ struct GroupLds {
   double cur[kWavesPerGroup][kCurParams];
   int resident;  // 1: tile 0 of the problem's only function sits in tiles[0] (FnDesc::solo)
 };
-constexpr unsigned kSweepLdsBytes = sizeof(LdsHead);  // dynamic LDS of k_split_sweep
+// dynamic LDS of k_split_sweep: the tables and, per wave, the proposal it judges and the model's
+// scratch (dynamic, not __shared__ arrays: static LDS would sit in front of the tables, which the
+// device math reads at absolute addresses - mhx_device.hpp)
+struct SweepLds {
+  LdsHead head;
+  double prop[kWavesPerGroup][MHX_MAX_PARAMS];
+  double scr[kWavesPerGroup][MHX_MAX_FN_PARAMS + 4];  // (model_wants_scratch)
+};
+constexpr unsigned kSweepLdsBytes = sizeof(SweepLds);
+static_assert(__builtin_offsetof(SweepLds, head) == 0, "the tables must lead the dynamic LDS");
 // 160 KiB of LDS per CU: one workgroup of the 16-wave family, TWO of the 8-wave family
 static_assert(sizeof(GroupLds) * (kWavesPerGroup <= 8 ? 2 : 1) <= 160 * 1024,
               "GroupLds no longer fits the workgroups per CU its kernel family counts on");
@@ -1804,19 +1813,18 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
 template <class Spec>
 __device__ __forceinline__ void k_split_sweep_body(const ProblemDesc* __restrict__ Pp,
                                                    ChainState S) {
-  __shared__ double sprop[kWavesPerGroup][MHX_MAX_PARAMS];
-  __shared__ double sscr[kWavesPerGroup][MHX_MAX_FN_PARAMS + 4];  // (model_wants_scratch)
+  SweepLds& sl = *reinterpret_cast<SweepLds*>(mhx_lds_raw);
   const ProblemDesc& P = *Pp;
   const int w = wave_in_group(), l = lane_id(), d = P.d;
   const int64_t c = blockIdx.y;
   if (__builtin_amdgcn_readfirstlane(S.split_pending[c]) == 0) return;  // nothing to judge
-  // the tables of tlog() (Poisson terms, log() in user expressions) and mexp2_negsq(): this
-  // kernel's whole dynamic LDS (kSweepLdsBytes), at the offsets every other kernel keeps them
+  // the tables of tlog() (Poisson terms, log() in user expressions) and mexp2_negsq() lead this
+  // kernel's dynamic LDS (SweepLds) as they lead every other kernel's
   lds_tables_begin();
   __syncthreads();
   const int slot = (int)blockIdx.x * kWavesPerGroup + w;
-  if (l < d) sprop[w][l] = S.split_prop[c * d + l];
-  const double* th = sprop[w];
+  if (l < d) sl.prop[w][l] = S.split_prop[c * d + l];
+  const double* th = sl.prop[w];
   for (int k = 0; k < P.K; ++k) {
     const FnDesc& f = P.fn[k];
     auto pf = [&](int j) -> double { return th[f.idx[j]]; };
@@ -1825,7 +1833,7 @@ __device__ __forceinline__ void k_split_sweep_body(const ProblemDesc* __restrict
     const int64_t per = (pairs + S.split_slots - 1) / S.split_slots;
     const int64_t b0 = (int64_t)slot * per, b1 = b0 + per < pairs ? b0 + per : pairs;
     double v = 0.0;
-    if (b0 < b1) v = Spec::loglik_part(f, pf, b0 * 2 * kWave, b1 * 2 * kWave, sscr[w]);
+    if (b0 < b1) v = Spec::loglik_part(f, pf, b0 * 2 * kWave, b1 * 2 * kWave, sl.scr[w]);
     if (l == 0) S.split_part[(c * P.K + k) * S.split_slots + slot] = v;
   }
 }

@@ -478,6 +478,16 @@ static int build_once(const std::vector<UserExpr>& models, const std::vector<Use
       return -1;
     }
   }
+  // (the device math reads its tables at absolute LDS addresses: no static LDS in these kernels)
+  auto static_lds = [](hipFunction_t f) {
+    int v = 0;
+    return hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, f) == hipSuccess ? v : -1;
+  };
+  for (auto& x : fs)
+    if (static_lds(*x.f) != 0) {
+      *err = std::string("module function ") + x.n + " has static LDS";
+      return -1;
+    }
   prog->has_split = false;
   if (with_split) {
     he = hipModuleGetFunction(&prog->f_split_sweep, prog->module, "mhx_user_split_sweep");
@@ -488,6 +498,10 @@ static int build_once(const std::vector<UserExpr>& models, const std::vector<Use
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)fam.lds_bytes);
     if (he != hipSuccess) {
       *err = std::string("split-mode module functions: ") + hipGetErrorString(he);
+      return -1;
+    }
+    if (static_lds(prog->f_split_sweep) != 0 || static_lds(prog->f_split_step) != 0) {
+      *err = "split-mode module functions have static LDS";
       return -1;
     }
     prog->has_split = true;
