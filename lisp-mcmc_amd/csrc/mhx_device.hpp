@@ -88,9 +88,10 @@ __device__ __forceinline__ mhx_double2 exp2tab_entry(int lo) {
       : "v"(lo));
   return ((lds_cd2ptr_t)(__UINTPTR_TYPE__)a)[kLdsExp2Tab / 16];
 }
-// {1/c_i, log c_i} of kLogTab for i = bits 13..19 of `th`
-__device__ __forceinline__ mhx_double2 logtab_entry(unsigned th) {
-  const unsigned a = (th >> 9) & 0x7F0u;
+// {1/c_i, log c_i} for the high word hx of the argument: LDS slot (hx >> 13) & 127, which
+// lds_tables_begin() fills with entry i = ((hx - 0x3FE60000) >> 13) & 127 of kLogTab
+__device__ __forceinline__ mhx_double2 logtab_entry(unsigned hx) {
+  const unsigned a = (hx >> 9) & 0x7F0u;
   return ((lds_cd2ptr_t)(__UINTPTR_TYPE__)a)[kLdsLogTab / 16];
 }
 
@@ -408,8 +409,8 @@ __device__ __forceinline__ double mexp2_negsq_safe(double t) {
 // v_rcp_f64 + two Newton steps instead of an IEEE division.  < 1 ulp on normal positive x.
 // x <= 0, subnormal, inf or NaN -> NaN: a rate outside (0, inf) is where the reference errors
 // (log of a negative number is complex, log 0 traps), and a NaN log-posterior freezes the chain.
-// (out of line like dexp: it only serves rates within 1/16 of 1 and the arguments that end in NaN,
-// and inlined its constants took registers from the Poisson kernel's loops)
+// (out of line like dexp: it only serves the logs of user expressions within 1/16 of 1 and the
+// arguments that end in NaN)
 __device__ __attribute__((noinline)) double mlog(double x) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
@@ -443,13 +444,23 @@ __device__ __attribute__((noinline)) double mlog(double x) {
   const bool ok = (unsigned int)(hx0 - 0x00100000) < (unsigned int)(0x7ff00000 - 0x00100000);
   return ok ? r : __builtin_nan("");
 }
-// log(x) for the Poisson sweep, table driven (Tang 1990): x = 2^k z, z in [0.6875, 1.375), the
-// top 7 mantissa bits of z pick c_i; r = z/c_i - 1 (one fma, |r| < 2^-7.6);
+// log(x), table driven (Tang 1990): x = 2^k z, z in [0.6875, 1.375), the top 7 mantissa bits of
+// z pick c_i; r = z/c_i - 1 (one fma, |r| < 2^-7.6);
 // log x = (k ln2_hi + log c_i) + r + [k ln2_lo + log1p(r) - r].  The bracket sum is exact (both
 // terms are multiples of 2^-43) and log c_i is tabulated to 2^-68 (tools/gen_log_table.py), so the
-// result stays below 0.7 ulp (checked against 80-bit logl on 4e7 arguments) in 25 VALU
-// instructions + one ds_read_b128, where mlog() needs 42.  Arguments within 1/16 of 1 - where
-// the table terms cancel - and everything mlog() answers with NaN go through mlog().
+// result stays below 0.7 ulp (checked against 80-bit logl on 4e7 arguments) outside 1/16 of 1,
+// where the table terms cancel: there the ABSOLUTE error stays below 2^-56
+// (tests/test_device_math_cpu.py).  Two entry points:
+//   tlog_rate(x)  the Poisson sweep's k log(lambda) (M:383): the table form everywhere (a term
+//                 k log(lambda) - lambda near lambda = 1 is of size 1: 2^-56 is nothing to it);
+//                 x <= 0, subnormal, inf or NaN -> NaN.  20 VALU instructions + one ds_read_b128.
+//   tlog(x)       (log x) of a user expression: within 1/16 of 1 through mlog() (< 1 ulp there
+//                 too), and so is everything mlog() answers with NaN.
+// In instructions: the table is indexed by the mantissa bits of x itself (the LDS copy is rotated
+// by OFF's 48 entries: lds_tables_begin), -k comes out of one subtraction and one shift, z out of
+// one v_ldexp_f64 (the same bits as subtracting k from the exponent field, which took an and, a
+// subtraction and a register copy), and A1 enters as the addend of a three-register fma (as the
+// addend of the fma with the literal -1/4 it was copied into the destination first, every call).
 __device__ const double kLogTab[128][2] = {
 #include "mhx_log_table.inc"
 };
@@ -462,28 +473,34 @@ __device__ __forceinline__ double tlog_a3() {
   asm volatile("" : "+v"(v));
   return v;
 }
-__device__ __forceinline__ double tlog(double x, lds_cdptr_t tab, double A3 = kTlogA3) {
-  const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
+__device__ __forceinline__ double tlog_table(double x, unsigned hx, double A3) {
+  const double nLn2hi = -0x1.62e42fefa3800p-1, nLn2lo = -0x1.ef35793c76730p-45;
   const double A1 = 0x1.5555555555555p-2, A4 = -0x1.5555555555555p-3;
-  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
-  const unsigned hx = (unsigned)(b >> 32), lx = (unsigned)b;
-  const unsigned th = hx - 0x3FE60000u;  // high word of bits(x) - OFF (OFF's low word is 0)
-  const mhx_double2 ic = logtab_entry(th);  // entry (th >> 13) & 127
-  const int k = (int)th >> 20;
-  const unsigned zh = hx - (th & 0xFFF00000u);
-  const double z = __longlong_as_double((long long)(((unsigned long long)zh << 32) | lx));
-  const double invc = ic.x, logc = ic.y;
-  (void)tab;
-  const double r = __builtin_fma(z, invc, -1.0);
-  const double kd = (double)k;
-  const double w = __builtin_fma(kd, Ln2hi, logc);  // exact
+  const mhx_double2 ic = logtab_entry(hx);               // {1/c_i, log c_i}
+  // -k, k = floor((hx - OFF) / 2^20) with OFF = 0x3FE60000: ceil((OFF - hx) / 2^20)
+  const int nk = (int)(0x3FE60000u + 0x000FFFFFu - hx) >> 20;
+  const double z = ldexp(x, nk);                         // exact
+  const double r = __builtin_fma(z, ic.x, -1.0);
+  const double nkd = (double)nk;
+  const double w = __builtin_fma(nkd, nLn2hi, ic.y);     // exact
   const double hi = w + r;
-  const double lo = __builtin_fma(kd, Ln2lo, (w - hi) + r);
+  const double lo = __builtin_fma(nkd, nLn2lo, (w - hi) + r);
   const double r2 = r * r;
-  const double p1 = __builtin_fma(r, A4, A3), p2 = __builtin_fma(r, -0.25, A1);
-  const double p3 = __builtin_fma(r2, p1, p2);
+  const double p1 = __builtin_fma(r, A4, A3);
+  const double p3 = __builtin_fma(r, -0.25, __builtin_fma(r2, p1, A1));
   const double t = __builtin_fma(r2, -0.5, lo);
-  double res = __builtin_fma(r * r2, p3, t) + hi;
+  return __builtin_fma(r * r2, p3, t) + hi;
+}
+__device__ __forceinline__ double tlog_rate(double x, double A3 = kTlogA3) {
+  const unsigned hx = (unsigned)((unsigned long long)__double_as_longlong(x) >> 32);
+  const unsigned long long rb = (unsigned long long)__double_as_longlong(tlog_table(x, hx, A3));
+  // positive and normal, or the high word of a NaN (one v_cmp_class_f64, one v_cndmask_b32)
+  const unsigned rh = __builtin_amdgcn_class(x, 0x100u) ? (unsigned)(rb >> 32) : 0x7FF80000u;
+  return __longlong_as_double((long long)(((unsigned long long)rh << 32) | (unsigned)rb));
+}
+__device__ __forceinline__ double tlog(double x, double A3 = kTlogA3) {
+  const unsigned hx = (unsigned)((unsigned long long)__double_as_longlong(x) >> 32);
+  double res = tlog_table(x, hx, A3);
   // normal, positive, finite and not within 1/16 of 1: one unsigned compare each
   const bool ordinary = (unsigned)(hx - 0x00100000u) < (unsigned)(0x7ff00000u - 0x00100000u);
   const bool near_one = (unsigned)(hx - 0x3FEE0000u) < (unsigned)(0x3FF10000u - 0x3FEE0000u);

@@ -59,7 +59,8 @@ static_assert(__builtin_offsetof(GroupLds, head) == 0, "the tables must lead the
 __device__ __forceinline__ void lds_tables_begin() {
   LdsHead& h = *reinterpret_cast<LdsHead*>(mhx_lds_raw);
   const int t = threadIdx.x;  // (every workgroup has >= 256 threads... or loops)
-  for (int i = t; i < 256; i += blockDim.x) h.logtab[i] = kLogTab[i >> 1][i & 1];
+  // (slot s holds entry (s - 48) & 127: logtab_entry() indexes by the argument's own mantissa bits)
+  for (int i = t; i < 256; i += blockDim.x) h.logtab[i] = kLogTab[((i >> 1) + 80) & 127][i & 1];
   for (int i = t; i < 512; i += blockDim.x) h.exp2tab[i >> 1][i & 1] = kExp2Tab[i >> 1][i & 1];
 }
 __device__ __forceinline__ void lds_begin(GroupLds& lds) {
@@ -633,7 +634,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
                 acc = acc + ((kWhole || gi < f.n) ? tt : 0.0);
               } else {
                 // (- (* k (log lambda)) lambda ...) M:383; pads masked (no neutral pad exists)
-                const double tt = __builtin_fma(y[i], tlog(m[i], lds_logtab(), log_a3), -m[i]);
+                const double tt = __builtin_fma(y[i], tlog_rate(m[i], log_a3), -m[i]);
                 acc = acc + ((kWhole || gi < f.n) ? tt : 0.0);
               }
             }
@@ -782,8 +783,7 @@ __device__ __forceinline__ double sweep_direct(const FnDesc& f, const typename M
       acc0 = acc0 + (i0 < f.n ? t0 : 0.0);
       acc1 = acc1 + (i1 < f.n ? t1 : 0.0);
     } else {
-      const lds_cdptr_t tab = lds_logtab();
-      const double t0 = __builtin_fma(y0, tlog(m0, tab), -m0), t1 = __builtin_fma(y1, tlog(m1, tab), -m1);
+      const double t0 = __builtin_fma(y0, tlog_rate(m0), -m0), t1 = __builtin_fma(y1, tlog_rate(m1), -m1);
       acc0 = acc0 + (i0 < f.n ? t0 : 0.0);
       acc1 = acc1 + (i1 < f.n ? t1 : 0.0);
     }
@@ -827,9 +827,8 @@ __device__ __forceinline__ double sweep_direct_rec(const FnDesc& f,
         acc1 = __builtin_fma(r1, r1, acc1);
       } else {
         static_assert(LIK == MHX_LIK_NORMAL || LIK == MHX_LIK_POISSON, "likelihoods of the peaks kernels");
-        const lds_cdptr_t tab = lds_logtab();
-        const double t0 = __builtin_fma(y0, tlog(m[0], tab), -m[0]);
-        const double t1 = __builtin_fma(y1, tlog(m[1], tab), -m[1]);
+        const double t0 = __builtin_fma(y0, tlog_rate(m[0]), -m[0]);
+        const double t1 = __builtin_fma(y1, tlog_rate(m[1]), -m[1]);
         acc0 = acc0 + (i0 < f.n ? t0 : 0.0);
         acc1 = acc1 + (i1 < f.n ? t1 : 0.0);
       }

@@ -185,7 +185,7 @@ static std::string generate(const std::vector<UserExpr>& models,
     << (ocml ? "exp(a)" : "gexp(a)") << "; }\n"
     << "__device__ __forceinline__ double mhx_ux_log(double a) { return "
     << (ocml ? "(a > 0.0 ? log(a) : __builtin_nan(\"\"))"
-             : "tlog(a, lds_logtab())")
+             : "tlog(a)")
     << "; }\n";
   // Divisions by expressions that do not depend on x (1/w, 1/tau ...) are loop invariant; with
   // reciprocal math the compiler forms the reciprocal once per step instead of dividing per

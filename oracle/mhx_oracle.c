@@ -521,10 +521,9 @@ static double mir_mexp2(double s) {
   return ldexp(p, (int)kf);
 }
 
-/* csrc/mhx_device.hpp: tlog, the table-driven log of the Poisson term (Tang's method, the SAME
- * generated table).  Arguments within 1/16 of 1, and everything that is not a positive normal
- * number, go through mlog() on the device, whose quotient starts from the hardware's v_rcp_f64
- * - not an IEEE operation, so not restated: *plain is cleared and the mirror declines. */
+/* csrc/mhx_device.hpp: tlog_rate, the table-driven log of the Poisson term (Tang's method, the
+ * SAME generated table; the device forms z with one ldexp and -k with one subtraction - the same
+ * numbers as below).  Everything that is not a positive normal number is a NaN there and here. */
 static const double mir_log_tab[128][2] = {
 #include "../lisp-mcmc_amd/csrc/mhx_log_table.inc"
 };
@@ -545,14 +544,14 @@ static double mir_tlog(double x, int* plain) {
   const double hi = w + r;
   const double lo = fma(kd, Ln2lo, (w - hi) + r);
   const double r2 = r * r;
-  const double p1 = fma(r, A4, A3), p2 = fma(r, -0.25, A1);
-  const double p3 = fma(r2, p1, p2);
+  const double p1 = fma(r, A4, A3);
+  const double p3 = fma(r, -0.25, fma(r2, p1, A1));
   const double t = fma(r2, -0.5, lo);
   const double res = fma(r * r2, p3, t) + hi;
+  /* tlog_rate(): positive and normal, else NaN (v_cmp_class_f64 on the device) */
   const int ordinary = (uint32_t)(hx - 0x00100000u) < (uint32_t)(0x7ff00000u - 0x00100000u);
-  const int near_one = (uint32_t)(hx - 0x3FEE0000u) < (uint32_t)(0x3FF10000u - 0x3FEE0000u);
-  if (!ordinary || near_one) *plain = 0;
-  return res;
+  (void)plain;
+  return ordinary ? res : NAN;
 }
 
 /* csrc/mhx_engine.cpp, mhx_set_dataset: x is a uniform grid x_0 + i h to 8 ulp of max |x| ->
