@@ -446,14 +446,14 @@ __device__ __attribute__((noinline)) double mlog(double x) {
 }
 // log(x), table driven (Tang 1990): x = 2^k z, z in [0.6875, 1.375), the top 7 mantissa bits of
 // z pick c_i; r = z/c_i - 1 (one fma, |r| < 2^-7.6);
-// log x = (k ln2_hi + log c_i) + r + [k ln2_lo + log1p(r) - r].  The bracket sum is exact (both
+// log x = (k ln2_hi + log c_i) + [k ln2_lo + log1p(r)].  The first sum is exact (both
 // terms are multiples of 2^-43) and log c_i is tabulated to 2^-68 (tools/gen_log_table.py), so the
 // result stays below 0.7 ulp (checked against 80-bit logl on 4e7 arguments) outside 1/16 of 1,
 // where the table terms cancel: there the ABSOLUTE error stays below 2^-56
 // (tests/test_device_math_cpu.py).  Two entry points:
 //   tlog_rate(x)  the Poisson sweep's k log(lambda) (M:383): the table form everywhere (a term
 //                 k log(lambda) - lambda near lambda = 1 is of size 1: 2^-56 is nothing to it);
-//                 x <= 0, subnormal, inf or NaN -> NaN.  20 VALU instructions + one ds_read_b128.
+//                 x <= 0, subnormal, inf or NaN -> NaN.  18 VALU instructions + one ds_read_b128.
 //   tlog(x)       (log x) of a user expression: within 1/16 of 1 through mlog() (< 1 ulp there
 //                 too), and so is everything mlog() answers with NaN.
 // In instructions: the table is indexed by the mantissa bits of x itself (the LDS copy is rotated
@@ -483,13 +483,14 @@ __device__ __forceinline__ double tlog_table(double x, unsigned hx, double A3) {
   const double r = __builtin_fma(z, ic.x, -1.0);
   const double nkd = (double)nk;
   const double w = __builtin_fma(nkd, nLn2hi, ic.y);     // exact
-  const double hi = w + r;
-  const double lo = __builtin_fma(nkd, nLn2lo, (w - hi) + r);
   const double r2 = r * r;
   const double p1 = __builtin_fma(r, A4, A3);
   const double p3 = __builtin_fma(r, -0.25, __builtin_fma(r2, p1, A1));
-  const double t = __builtin_fma(r2, -0.5, lo);
-  return __builtin_fma(r * r2, p3, t) + hi;
+  // w + [(k ln2_lo + r) + r^2 (-1/2 + r p3)]: the bracket is below 2^-7 and carries its rounding
+  // errors at that scale, the one rounding that counts is the last addition's
+  const double a = __builtin_fma(nkd, nLn2lo, r);
+  const double q = __builtin_fma(r, p3, -0.5);
+  return w + __builtin_fma(r2, q, a);
 }
 __device__ __forceinline__ double tlog_rate(double x, double A3 = kTlogA3) {
   const unsigned hx = (unsigned)((unsigned long long)__double_as_longlong(x) >> 32);

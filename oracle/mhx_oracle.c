@@ -541,13 +541,12 @@ static double mir_tlog(double x, int* plain) {
   const double r = fma(z, invc, -1.0);
   const double kd = (double)k;
   const double w = fma(kd, Ln2hi, logc);
-  const double hi = w + r;
-  const double lo = fma(kd, Ln2lo, (w - hi) + r);
   const double r2 = r * r;
   const double p1 = fma(r, A4, A3);
   const double p3 = fma(r, -0.25, fma(r2, p1, A1));
-  const double t = fma(r2, -0.5, lo);
-  const double res = fma(r * r2, p3, t) + hi;
+  const double a = fma(kd, Ln2lo, r);
+  const double q = fma(r, p3, -0.5);
+  const double res = w + fma(r2, q, a);
   /* tlog_rate(): positive and normal, else NaN (v_cmp_class_f64 on the device) */
   const int ordinary = (uint32_t)(hx - 0x00100000u) < (uint32_t)(0x7ff00000u - 0x00100000u);
   (void)plain;

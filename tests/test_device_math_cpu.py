@@ -55,13 +55,12 @@ static double tlog(double x) {
   double invc = T[i][0], logc = T[i][1];
   double r = fma(z, invc, -1.0), kd = (double)k;
   double w = fma(kd, Ln2hi, logc);
-  double hi = w + r;
-  double lo = fma(kd, Ln2lo, (w - hi) + r);
   double r2 = r * r;
   double p1 = fma(r, A4, A3);
   double p3 = fma(r, -0.25, fma(r2, p1, A1));
-  double t = fma(r2, -0.5, lo);
-  return fma(r * r2, p3, t) + hi;
+  double a = fma(kd, Ln2lo, r);
+  double q = fma(r, p3, -0.5);
+  return w + fma(r2, q, a);
 }
 int main(void) {
   double maxu = 0, maxa = 0; srand48(3);
