@@ -542,14 +542,15 @@ __device__ __attribute__((noinline)) double dexp(double x) {
   return ldexp(p, (int)kf);
 }
 
-// 1/d from v_rcp_f64 and two Newton steps (<= 1 ulp; inf/NaN/0 behave like a division):
-// 5 instructions instead of the ~25 of an IEEE fp64 division.  Used for the Lorentzian
-// 1/(1+u^2), whose denominator is >= 1.
+// 1/d from v_rcp_f64 and ONE cubic correction, y (1 + e + e^2) with e = 1 - d y: 4 instructions
+// instead of the ~25 of an IEEE fp64 division.  v_rcp_f64 is good to 2^-24.4 on gfx950
+// (tools/microbench/rcp_error.hip), so e^3 = 2^-73 and the result is within 2^-53.0 of 1/d -
+// what two quadratic (Newton) steps give in 5.  Used for the Lorentzian 1/(1+u^2), whose
+// denominator is >= 1 and finite.
 __device__ __forceinline__ double frcp(double d) {
-  double y = __builtin_amdgcn_rcp(d);
-  y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
-  y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
-  return y;
+  const double y = __builtin_amdgcn_rcp(d);
+  const double e = __builtin_fma(-d, y, 1.0);
+  return __builtin_fma(y, __builtin_fma(e, e, e), y);
 }
 // e^x, < 1 ulp: the `exp` of user expressions (mhx_rtc.cpp) - 17 VALU instructions where
 // ocml's exp takes about 37.  k = rint(x log2 e) by the magic-number trick, f = x log2 e - k
@@ -1310,11 +1311,12 @@ struct PVoigt2Model {
     // operand, and left in scalar registers these three were copied into a vector register in
     // every iteration of the tile loop (3 v_mov_b64 per 2 points: 1.5 of 55 instructions per point)
     {
-      double c1v = p.c1, c2v = p.c2p, b0v = p.b0;
+      double c1v = p.c1, c2v = p.c2p, b0v = p.b0, b1v = p.b1;
       asm volatile("" : "+v"(c1v));
       asm volatile("" : "+v"(c2v));
       asm volatile("" : "+v"(b0v));
-      p.c1 = c1v; p.c2p = c2v; p.b0 = b0v;
+      asm volatile("" : "+v"(b1v));  // (Horner's inner fma reads c2 from the scalar file)
+      p.c1 = c1v; p.c2p = c2v; p.b0 = b0v; p.b1 = b1v;
     }
     const double e1 = fabs(__builtin_fma(fn.xmin, p.g1w, p.g1c)), e2 = fabs(__builtin_fma(fn.xmax, p.g1w, p.g1c));
     const double e3 = fabs(__builtin_fma(fn.xmin, p.g2w, p.g2c)), e4 = fabs(__builtin_fma(fn.xmax, p.g2w, p.g2c));
@@ -1353,7 +1355,7 @@ struct PVoigt2Model {
     const double l1 = y * d2, l2 = y * d1;
     // A (pv1 + rho pv2) + bg with the four products of its constants formed once per step:
     // four fmas on top of the background where the nested form takes six operations
-    double f = __builtin_fma(p.c2, x * x, __builtin_fma(p.b1, x, p.b0));
+    double f = __builtin_fma(__builtin_fma(p.c2, x, p.b1), x, p.b0);  // Horner: 2, not 3
     f = __builtin_fma(p.k1, l1, f);
     f = __builtin_fma(p.k2, g1, f);
     f = __builtin_fma(p.k3, l2, f);
