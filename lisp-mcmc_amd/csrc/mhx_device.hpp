@@ -685,6 +685,26 @@ struct PeaksModel {
   static __device__ __forceinline__ void rec_seed_bg(const Prep& p, double x0, Rec& rs) {
     rs.b = bg_of(p, x0);
   }
+  // The same for a mask known only at run time (the seeds INSIDE a window: sweep()), peak by peak
+  // behind scalar branches.  As one batch with run-time `on` flags the compiler evaluates every
+  // exp of the batch and selects: 80 instructions, 56 of them v_cndmask, where one peak's seed
+  // takes 28.  Per exp the operations are the batch's: identical bits.
+  static __device__ __forceinline__ void rec_seed_some(const Prep& p, double x0, unsigned mask,
+                                                       Rec& rs) {
+    const unsigned sm = (unsigned)__builtin_amdgcn_readfirstlane((int)mask);
+#pragma unroll
+    for (int k = 0; k < NPK; ++k) {
+      if (!((sm >> k) & 1u)) continue;
+      double t[2], v[2];
+      const bool on[2] = {true, true};
+      if constexpr (kSeedInLds) t[0] = __builtin_fma(x0, p.iw_of(k), p.c_of(k));
+      else t[0] = fma_svv(x0, p.iw[k], p.cv[k]);
+      t[1] = __builtin_fma(p.rm2d_of(k), t[0], p.rnd2_of(k));
+      mexp2_negsq_batch<2, true>(t, on, p.K, v);
+      rs.g[k] = v[0];
+      rs.r[k] = v[1];
+    }
+  }
   // x0: the lane's x at the first point of the window; mask: the peaks to seed (those
   // that are evaluated in this tile AND go by the recurrence)
   static __device__ __forceinline__ void rec_seed(const Prep& p, double x0, unsigned mask, Rec& rs) {

@@ -602,7 +602,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
                   // narrower peaks, seeded every kSeedPts / 2 or / 4 points of the lane
                   // (PeaksModel::prepare): run-time masks, wave-uniform, rarely non-zero
                   const unsigned ms = (gp % (kSeedPts / 2) == 0 ? seed16 : seed8) & rm & mask;
-                  if (ms != 0u) Model::rec_seed(prep, x[0], ms, rs);
+                  if (ms != 0u) Model::rec_seed_some(prep, x[0], ms, rs);
                 }
                 Model::template eval_mixed<P, BGREC>(prep, x, mask, rm, rs, m);
               } else {
