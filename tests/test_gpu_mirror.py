@@ -194,6 +194,35 @@ def test_poisson_logpost_equals_mirror(mhx, orc, n, logfact_double):
     e.close()
 
 
+@pytest.mark.parametrize("n", [64, 3000])
+def test_poisson_rates_near_one_and_outside_the_log(mhx, orc, n):
+    """tlog_rate (csrc/mhx_device.hpp) keeps the table form within 1/16 of 1 (where the user
+    expressions' tlog detours through mlog) and answers everything that is not a positive normal
+    number with a NaN: rates 0.94 .. 1.06 equal the mirror bit for bit and the faithful sum
+    within the tolerance; a background that makes the rate negative somewhere is a NaN on the
+    device, in the mirror and in the faithful oracle (M:383: log of a negative rate)"""
+    s = pb.poisson_peaks(n=n, seed=5 + n)
+    op = s.oracle(orc)
+    e = s.engine(mhx, 1)
+    th = np.tile(s.theta_star, (8, 1))
+    for i in range(6):
+        th[i, 0] = 0.94 + 0.024 * i          # the background alone ...
+        th[i, 1::3] = 1e-3 * i               # ... under peaks of height 0 .. 5e-3
+    th[6, 0] = -30.0                         # rate < 0 between the peaks
+    th[7, 0] = 0.0
+    th[7, 1::3] = 0.0                        # rate == 0 everywhere
+    got, parts = e.logpost(th, parts=True)
+    for i, t in enumerate(th):
+        ref, rp = op.logpost_mirror(t, parts=True)
+        if i < 6:
+            assert np.isfinite(ref) and got[i] == ref and parts[i, 0] == rp[0], (n, i, got[i], ref)
+            fa, fp = op.logpost(t, parts=True)   # (the likelihood part: the prior is far outside its box)
+            assert abs(parts[i, 0] - fp[0]) <= 1e-12 * op.abs_terms(t), (n, i)
+        else:
+            assert np.isnan(got[i]) and np.isnan(ref), (n, i, got[i], ref)
+    e.close()
+
+
 def test_poisson_walk_equals_mirror(mhx, orc):
     s = pb.poisson_peaks(n=6000, seed=77)
     op = s.oracle(orc)
