@@ -552,32 +552,34 @@ __device__ __forceinline__ double frcp(double d) {
   const double e = __builtin_fma(-d, y, 1.0);
   return __builtin_fma(y, __builtin_fma(e, e, e), y);
 }
-// e^x, < 1 ulp: the `exp` of user expressions (mhx_rtc.cpp) - 17 VALU instructions where
-// ocml's exp takes about 37.  k = rint(x log2 e) by the magic-number trick, f = x log2 e - k
-// from a hi/lo split of log2 e (the inner fma cancels k, so f keeps an absolute error of
-// 2^-54), 2^f by mexp2's polynomial, scaled by ldexp with the SATURATING conversion of k, so
-// that x > 709.8 gives inf and x < -745.2 gives 0 with no range test.  NaN -> NaN.  x = +-inf
-// -> NaN as well: an infinite argument can only come from an operation SBCL would already have
-// trapped on (overflow), and a NaN log-posterior marks the chain as trapped.  For finite
-// |x| >= 2^51 / log2 e the result is 0 or an infinity of either sign.
+// e^x, < 1 ulp: the `exp` of user expressions (mhx_rtc.cpp) - 15 VALU instructions and one LDS
+// read where ocml's exp takes about 37 (round 2's polynomial form: 18).  x log2 e = k + j/256 + r
+// by the magic-number trick (low dword of kd = 256 k + j), r from a hi/lo split of log2 e (the
+// inner fma cancels k + j/256, so r keeps an absolute error of 2^-62), 2^(j/256) from
+// mexp2_negsq's table, 2^r - 1 by its cubic, the scale by v_ldexp_f64 - which overflows to inf
+// (x > 709.8) and underflows to 0 (x < -745.2) by itself.  The trick needs |x log2 e| < 2^22:
+// beyond |x| = 1000 the answer is known - inf or 0 for finite x; NaN -> NaN, and x = +-inf ->
+// NaN as well: an infinite argument can only come from an operation SBCL would already have
+// trapped on (overflow), and a NaN log-posterior marks the chain as trapped.
 __device__ __forceinline__ double gexp(double x) {
-  const double MAGIC = 0x1.8p52, L2E_HI = 0x1.71547652b82fep+0, L2E_LO = 0x1.777d0ffda0d24p-56;
+  const double MAGIC = 0x1.8p44, L2E_HI = 0x1.71547652b82fep+0, L2E_LO = 0x1.777d0ffda0d24p-56;
+  const double q3 = 0x1.3b2ab83eadfb0p-7, q2 = 0x1.c6b0902b5a0abp-5, q1 = 0x1.ebfbdff82c585p-3,
+               q0 = 0x1.62e42fefa39d9p-1;  // (Exp2K's constants)
   const double kd = __builtin_fma(x, L2E_HI, MAGIC);
   const double kf = kd - MAGIC;
-  const double f = __builtin_fma(x, L2E_LO, __builtin_fma(x, L2E_HI, -kf));
-  double p = 0x1.e9d3fe3952179p-32;
-  p = __builtin_fma(p, f, 0x1.e6063f7217bc6p-28);
-  p = __builtin_fma(p, f, 0x1.b524fae627834p-24);
-  p = __builtin_fma(p, f, 0x1.62bfd47773353p-20);
-  p = __builtin_fma(p, f, 0x1.ffcbfc670dcd4p-17);
-  p = __builtin_fma(p, f, 0x1.430913096fd9fp-13);
-  p = __builtin_fma(p, f, 0x1.5d87fe78a5276p-10);
-  p = __builtin_fma(p, f, 0x1.3b2ab6fba1ddap-7);
-  p = __builtin_fma(p, f, 0x1.c6b08d704a0c2p-5);
-  p = __builtin_fma(p, f, 0x1.ebfbdff82c598p-3);
-  p = __builtin_fma(p, f, 0x1.62e42fefa39efp-1);
-  p = __builtin_fma(p, f, 1.0);
-  return ldexp(p, (int)kf);  // v_cvt_i32_f64 saturates
+  const double r = __builtin_fma(x, L2E_LO, __builtin_fma(x, L2E_HI, -kf));
+  const int lo = (int)__double_as_longlong(kd);
+  const mhx_double2 e = exp2tab_entry(lo);
+  double a = __builtin_fma(r, q3, q2);
+  a = __builtin_fma(r, a, q1);
+  a = __builtin_fma(r, a, q0);
+  const double ee = __builtin_fma(r, a, e.y);
+  double v = ldexp(__builtin_fma(e.x, ee, e.x), lo >> 8);
+  // (a compare and two selects; as a branch it would cut the callers' batches of independent
+  // exps into dependent pieces)
+  if (!(fabs(x) <= 1000.0))
+    v = fabs(x) < __builtin_inf() ? (x > 0.0 ? __builtin_inf() : 0.0) : __builtin_nan("");
+  return v;
 }
 constexpr double kLog2e = 1.4426950408889634074;       // log2(e)
 constexpr double kSqrtLog2e = 1.2011224087864497594;   // sqrt(log2(e))

@@ -177,8 +177,8 @@ static std::string generate(const std::vector<UserExpr>& models,
        "  int nextn = power >> 1; double total = (power & 1) ? base : 1.0;\n"
        "  while (nextn != 0) { base = base * base; if (nextn & 1) total = base * total; nextn >>= 1; }\n"
        "  return neg ? 1.0 / total : total;\n}\n";
-  // exp / log: the engine's own < 1 ulp routines (17 and 25 VALU instructions - the log reads
-  // its table from LDS - against ocml's 37 and 93); MHX_EXPR_OCML_MATH=1 selects ocml's.  (log x) of x <= 0 is an error in the
+  // exp / log: the engine's own < 1 ulp routines (15 and 22 VALU instructions - both read a
+  // table from LDS - against ocml's 37 and 93); MHX_EXPR_OCML_MATH=1 selects ocml's.  (log x) of x <= 0 is an error in the
   // reference; here it is a NaN, which marks the chain as trapped.
   const bool ocml = getenv("MHX_EXPR_OCML_MATH") && atoi(getenv("MHX_EXPR_OCML_MATH")) != 0;
   s << "__device__ __forceinline__ double mhx_ux_exp(double a) { return "

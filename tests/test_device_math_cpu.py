@@ -11,6 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = os.path.join(ROOT, "lisp-mcmc_amd", "csrc", "mhx_device.hpp")
+EXP2_INC = os.path.join(ROOT, "lisp-mcmc_amd", "csrc", "mhx_exp2_table.inc")
 
 
 def table_text():
@@ -108,17 +109,22 @@ GEXP_SRC = r'''
 #include <stdint.h>
 #include <string.h>
 #include <stdlib.h>
-/* gexp() of csrc/mhx_device.hpp (the exp of user expressions), with C99 fma and a saturating
-   conversion like v_cvt_i32_f64 */
-static int sat_i32(double v) { return v >= 2147483647.0 ? 2147483647 : (v <= -2147483648.0 ? (-2147483647 - 1) : (int)v); }
+static const double T[256][2] = {
+#include "%s"
+};
+/* gexp() of csrc/mhx_device.hpp (the exp of user expressions) with C99 fma */
 static double gexp(double x) {
-  const double MAGIC = 0x1.8p52, L2E_HI = 0x1.71547652b82fep+0, L2E_LO = 0x1.777d0ffda0d24p-56;
-  const double c[12] = {%s};
+  const double MAGIC = 0x1.8p44, L2E_HI = 0x1.71547652b82fep+0, L2E_LO = 0x1.777d0ffda0d24p-56;
+  const double q3 = %s, q2 = %s, q1 = %s, q0 = %s;
   double kd = fma(x, L2E_HI, MAGIC), kf = kd - MAGIC;
-  double f = fma(x, L2E_LO, fma(x, L2E_HI, -kf));
-  double p = c[0];
-  for (int i = 1; i < 12; ++i) p = fma(p, f, c[i]);
-  return ldexp(p, sat_i32(kf));
+  double r = fma(x, L2E_LO, fma(x, L2E_HI, -kf));
+  uint64_t b; memcpy(&b, &kd, 8);
+  int32_t lo = (int32_t)(uint32_t)b;
+  double a = fma(r, q3, q2); a = fma(r, a, q1); a = fma(r, a, q0);
+  double ee = fma(r, a, T[lo & 255][1]);
+  double v = ldexp(fma(T[lo & 255][0], ee, T[lo & 255][0]), lo >> 8);
+  if (!(fabs(x) <= 1000.0)) v = fabs(x) < INFINITY ? (x > 0.0 ? INFINITY : 0.0) : NAN;
+  return v;
 }
 int main(void) {
   double maxu = 0; srand48(1);
@@ -129,7 +135,9 @@ int main(void) {
     if (u > maxu) maxu = u;
   }
   int ok = gexp(710.0) == INFINITY && gexp(-746.0) == 0.0 && gexp(0.0) == 1.0 && isnan(gexp(NAN))
-           && !isfinite(gexp(1e300)) /* inf or nan, never a finite number */;
+           && gexp(1e300) == INFINITY && gexp(-1e300) == 0.0 && gexp(999.9) == INFINITY
+           && gexp(-999.9) == 0.0 && isnan(gexp(INFINITY)) && isnan(gexp(-INFINITY))
+           && gexp(-745.0) > 0.0 /* a subnormal, not 0 */;
   printf("%%.4f %%d\n", maxu, ok);
   return 0;
 }
@@ -139,20 +147,21 @@ int main(void) {
 def test_expression_exp_stays_below_one_ulp():
     src = open(HDR).read()
     body = src[src.index("double gexp(double x)"):]
-    body = body[:body.index("return ldexp")]
-    coefs = [re.search(r"double p = (0x[0-9a-f.]+p[+-]\d+);", body).group(1)]
-    coefs += re.findall(r"__builtin_fma\(p, f, ([0-9a-fx.p+-]+)\);", body)
-    assert len(coefs) == 12 and coefs[-1] == "1.0", coefs
+    body = body[:body.index("return v;")]
+    q = [re.search(r"\b%s = (0x[0-9a-f.]+p[+-]\d+)" % n, body).group(1) for n in ("q3", "q2", "q1", "q0")]
+    # ... the same constants as the Gaussians' table exp (Exp2K::pin)
+    pin = src[src.index("struct Exp2K"):src.index("struct Exp2Head")]
+    for c in q:
+        assert c in pin, c
     d = tempfile.mkdtemp()
     c, exe = os.path.join(d, "g.c"), os.path.join(d, "g")
-    open(c, "w").write(GEXP_SRC % ", ".join(coefs))
+    open(c, "w").write(GEXP_SRC % ((EXP2_INC,) + tuple(q)))
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, c, "-lm"])
     worst, ok = subprocess.check_output([exe]).decode().split()
     assert float(worst) < 1.0 and ok == "1", (worst, ok)
 
 
 # ---- mexp2_negsq: the table-driven 2^(-t^2) of the Gaussian peaks --------------------------------
-EXP2_INC = os.path.join(ROOT, "lisp-mcmc_amd", "csrc", "mhx_exp2_table.inc")
 
 
 def test_exp2_table_properties():
