@@ -232,6 +232,10 @@ struct mhx_engine {
   int split_graph_plain = -1;
   DevBuf<double> split_prop, split_u, split_part;
   DevBuf<int32_t> split_pending;
+  // tile-sliced split mode (k_split_tsweep): split_slices = slices of whole windows per function,
+  // ts_table = their FnDescs [K][split_slices] on the device
+  bool tsplit = false;
+  DevBuf<FnDesc> ts_table;
   bool chains_ready = false;
 
   RunDesc R{};
@@ -345,6 +349,47 @@ int choose_split(const mhx_engine* e, const Family& fam, bool capable) {
                              : std::max<int64_t>(2, std::min<int64_t>(1024 / C, C < 32 ? 24 : 8));
   const int64_t slices = std::min<int64_t>(std::min<int64_t>(want, 24), by_data);
   return slices >= 2 ? (int)slices : 0;
+}
+
+// Tile-sliced split mode (k_split_tsweep): into how many slices of whole windows every function is
+// cut, each walked by the workgroups of ALL chain groups, or 0.  For batches too small to give
+// every CU a workgroup of the batch kernels and big enough to fill workgroups of their own:
+// about two workgroups per CU in the sweep launch.  MHX_TSPLIT=0 switches it off (the per-chain
+// split mode or the batch kernels then), MHX_TSPLIT=<n> asks for n slices; MHX_SPLIT=0 means the
+// batch kernels here too.
+int choose_tsplit(const mhx_engine* e, const Family& fam, bool capable) {
+  if (!capable || e->cfg.adapt_mode == MHX_ADAPT_POOLED) return 0;
+  int64_t longest = 0;
+  for (int k = 0; k < e->P.K; ++k) longest = std::max<int64_t>(longest, e->P.fn[k].n);
+  const int64_t nwin = (longest + kPadPoints - 1) / kPadPoints;
+  const int64_t C = e->cfg.n_chains;
+  const int W = fam.waves_per_group;
+  const int64_t groups = (C + W - 1) / W;
+  int64_t want = 0;
+  if (const char* s0 = getenv("MHX_SPLIT"))
+    if (atoi(s0) <= 0) return 0;  // "the batch kernels"
+  if (const char* s = getenv("MHX_TSPLIT")) {
+    want = atoi(s);
+    if (want <= 0) return 0;
+  } else {
+    // two launches and the step kernel cost about 17 us per iteration (64 chains of config 2's
+    // problem: 20.7 us with one window per workgroup): the fused batch kernel, 0.6-0.8 us per
+    // 1024-point tile when points are cheap, is quicker than that up to about two dozen tiles
+    bool heavy = false;
+    for (int k = 0; k < e->P.K; ++k) {
+      const FnDesc& fd = e->P.fn[k];
+      heavy = heavy || fd.lik == MHX_LIK_POISSON || fd.lik == MHX_LIK_EXPR ||
+              fd.model == MHX_MODEL_PVOIGT2 || fd.model == MHX_MODEL_EXPR;
+    }
+    if (C < W || groups >= 256 || nwin < (heavy ? 4 : 12)) return 0;
+    // measured (config 2's problem, chain-steps/s; slices 4 | 8 | 16 | 32 | 49):
+    //   64 chains 1.5e6 | 2.1e6 | 2.6e6 | 3.1e6 | 3.1e6     256: 6.0e6 | 7.9e6 | 8.0e6 | 7.0e6 | 6.3e6
+    //   1024: 1.47e7 | 1.33e7 | 1.13e7 | 9.2e6 | 8.8e6       (per-chain split mode: 2.4e6, 4.7e6; batch
+    //   kernels at 1024: 1.31e7) - about 512 workgroups in the sweep launch
+    want = 512 / groups;
+  }
+  want = std::min<int64_t>(want, nwin);
+  return want >= 2 ? (int)want : 0;
 }
 
 // Which workgroup shape serves this problem (mhx_types.hpp).  16 chains per workgroup and
@@ -474,7 +519,8 @@ int finalize_problem(mhx_engine* e) {
     }
     HIP_TRY(hipMemcpy(e->dP.p, &e->P, sizeof(ProblemDesc), hipMemcpyHostToDevice));
     std::string err;
-    const bool want_split = choose_split(e, *e->fam, !builtin) > 0;
+    const bool want_split =
+        choose_split(e, *e->fam, !builtin) > 0 || choose_tsplit(e, *e->fam, !builtin) > 0;
     std::shared_ptr<UserProgram> prog =
         rtc_get(models, priors, builtin, want_split, *e->fam, &err);
     if (prog) {
@@ -494,9 +540,43 @@ int finalize_problem(mhx_engine* e) {
   {
     const bool capable = e->spec == SPEC_USER ? e->user_prog->has_split
                                               : e->fam->split_capable(e->spec);
-    e->split_slices = choose_split(e, *e->fam, capable);
-    e->S.split_slots = e->split_slices * e->fam->waves_per_group;
+    const int ts = choose_tsplit(e, *e->fam, capable);
+    e->tsplit = ts > 0;
+    e->split_slices = e->tsplit ? ts : choose_split(e, *e->fam, capable);
+    e->S.split_slots = e->tsplit ? e->split_slices : e->split_slices * e->fam->waves_per_group;
     e->S.split_part = nullptr;
+    if (e->tsplit) {
+      // the slice table: function k, slice s = windows [s per_k, (s + 1) per_k) of its dataset
+      std::vector<FnDesc> tab((size_t)e->P.K * ts);
+      for (int k = 0; k < e->P.K; ++k) {
+        const FnDesc& f = e->P.fn[k];
+        const int64_t nwin = (f.n + kPadPoints - 1) / kPadPoints;
+        const int64_t per = (nwin + ts - 1) / ts;
+        for (int sl = 0; sl < ts; ++sl) {
+          FnDesc g = f;
+          const int64_t off = (int64_t)sl * per * kPadPoints;
+          g.lik_const = 0.0;
+          g.solo = 0;
+          if (off >= f.n) {
+            g.n = 0;
+            g.n_tiles = 0;
+          } else {
+            g.n = std::min<int64_t>(per * kPadPoints, f.n - off);
+            g.n_tiles = (g.n + e->fam->tile_points - 1) / e->fam->tile_points;
+            g.x = f.x + off;
+            g.y = f.y + off;
+            if (f.w) g.w = f.w + off;
+            if (f.c) g.c = f.c + off;
+            if (f.txlo) g.txlo = f.txlo + off / kPadPoints;
+            if (f.txhi) g.txhi = f.txhi + off / kPadPoints;
+          }
+          tab[(size_t)k * ts + sl] = g;
+        }
+      }
+      if (e->ts_table.alloc(tab.size(), false) != hipSuccess)
+        return fail(MHX_ENOMEM, "hipMalloc of the slice table failed");
+      HIP_TRY(hipMemcpy(e->ts_table.p, tab.data(), tab.size() * sizeof(FnDesc), hipMemcpyHostToDevice));
+    }
     if (e->split_slices > 0) {
       const size_t np = (size_t)e->cfg.n_chains * e->P.K * e->S.split_slots;
       if (e->split_part.alloc(np) != hipSuccess)
@@ -521,7 +601,8 @@ int finalize_problem(mhx_engine* e) {
     e->kernel_name += spec_name(e->spec);
     if (!e->rtc_note.empty()) e->kernel_name += " [not specialised: " + e->rtc_note + "]";
   }
-  if (e->split_slices > 0) e->kernel_name += " split x" + std::to_string(e->split_slices);
+  if (e->split_slices > 0)
+    e->kernel_name += (e->tsplit ? " tsplit x" : " split x") + std::to_string(e->split_slices);
   e->problem_dirty = false;
   return MHX_OK;
 }
@@ -543,6 +624,12 @@ hipError_t do_step_injected(mhx_engine* e, const double* L, int pcl, const doubl
              : e->fam->step_injected(e->spec, e->stream, e->dP.p, e->S, L, pcl, z, u, T, acc);
 }
 hipError_t do_split_sweep(mhx_engine* e) {
+  if (e->tsplit)
+    return e->spec == SPEC_USER
+               ? rtc_launch_split_tsweep(*e->user_prog, e->stream, e->dP.p, e->ts_table.p, e->S,
+                                         e->split_slices)
+               : e->fam->split_tsweep(e->spec, e->stream, e->dP.p, e->ts_table.p, e->S,
+                                      e->split_slices);
   return e->spec == SPEC_USER
              ? rtc_launch_split_sweep(*e->user_prog, e->stream, e->dP.p, e->S, e->split_slices)
              : e->fam->split_sweep(e->spec, e->stream, e->dP.p, e->S, e->split_slices);

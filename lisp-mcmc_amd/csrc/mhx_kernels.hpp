@@ -1841,6 +1841,52 @@ __global__ __launch_bounds__(kThreads) void k_split_sweep(const ProblemDesc* __r
                                                           ChainState S) {
   k_split_sweep_body<Spec>(Pp, S);
 }
+// split mode for 8 ... a few thousand chains ("tile-sliced"): block (slice g, group of chains b).
+// The 8 / 16 chains of a group walk the SAME slice of every function - whole windows, described
+// by a FnDesc of its own (the host's slice table: shifted pointers, its own n and n_tiles,
+// lik_const 0) - through the batch kernels' sweep(): LDS tiles shared by the group, peak
+// skipping, recurrence, yw tiles.  Where k_split_sweep has every wave read its points from the
+// L2 for itself (one chain's points over many workgroups: right for a handful of chains, bound by
+// the L2 from a few dozen on), this reads each point once per group.  The partial sums go where
+// k_split_sweep's go (slot = slice) and the step kernel adds them in slot order and finishes the
+// likelihood with the function's own constant.
+template <class Spec>
+__device__ __forceinline__ void k_split_tsweep_body(const ProblemDesc* __restrict__ Pp,
+                                                    const FnDesc* __restrict__ slices,
+                                                    ChainState S, int n_slices) {
+  GroupLds& lds = *reinterpret_cast<GroupLds*>(mhx_lds_raw);
+  lds_begin(lds);
+  const ProblemDesc& P = *Pp;
+  const int w = wave_in_group(), l = lane_id(), d = P.d;
+  const int slice = (int)blockIdx.x;
+  const int64_t c = (int64_t)blockIdx.y * kWavesPerGroup + w;
+  const bool valid = c < S.n_chains;
+  const bool active =
+      valid && __builtin_amdgcn_readfirstlane(S.split_pending[valid ? c : 0]) != 0;
+  // nothing to judge in this group?  (a flag of the dynamic LDS: __syncthreads_or() keeps a static
+  // __shared__ word, and static LDS would sit in front of the math tables - mhx_device.hpp)
+  if (active && l == 0) lds.vote[2] = 1;
+  __syncthreads();
+  if (__builtin_amdgcn_readfirstlane(*(volatile int*)&lds.vote[2]) == 0) return;
+  if (l < d) lds.prop[w][l] = active ? S.split_prop[c * d + l] : 0.0;
+  __syncthreads();
+  const double* th = lds.prop[w];
+  for (int k = 0; k < P.K; ++k) {
+    const FnDesc& f = slices[k * n_slices + slice];
+    auto pf = [&](int j) -> double { return th[f.idx[j]]; };
+    const double v = Spec::loglik(f, pf, active, lds, lds.prm[w]);
+    // loglik() finishes the sum with the slice's constant, 0: -s/2 (exact) for the normal
+    // likelihood, s for the others.  The step kernel finishes the whole sum: hand it s.
+    const double raw = f.lik == MHX_LIK_NORMAL ? -2.0 * v : v;
+    if (active && l == 0) S.split_part[(c * P.K + k) * S.split_slots + slice] = raw;
+  }
+}
+template <class Spec>
+__global__ __launch_bounds__(kThreads) void k_split_tsweep(const ProblemDesc* __restrict__ Pp,
+                                                           const FnDesc* __restrict__ slices,
+                                                           ChainState S, int n_slices) {
+  k_split_tsweep_body<Spec>(Pp, slices, S, n_slices);
+}
 // split mode, launch 2 of a step (and the priming / closing launches): see k_adaptive_body
 template <class Spec>
 __global__ __launch_bounds__(kThreads) void k_split_step(const ProblemDesc* __restrict__ Pp,

@@ -59,6 +59,10 @@ struct Family {
   bool (*split_capable)(int spec);
   hipError_t (*split_sweep)(int spec, hipStream_t st, const ProblemDesc* P, const ChainState& S,
                             int slices);
+  // ... or, tile-sliced (k_split_tsweep): groups of chains on slices of whole windows, `slices` =
+  // the device copy of the slice table [K][n_slices]
+  hipError_t (*split_tsweep)(int spec, hipStream_t st, const ProblemDesc* P, const FnDesc* slices,
+                             const ChainState& S, int n_slices);
   hipError_t (*split_step)(int spec, hipStream_t st, const ProblemDesc* P, const ChainState& S,
                            const RunDesc& R, int mode, int plain);
 };

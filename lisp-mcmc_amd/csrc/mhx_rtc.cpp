@@ -292,6 +292,9 @@ static std::string generate(const std::vector<UserExpr>& models,
     s << "extern \"C\" __global__ __launch_bounds__(MHX_USER_THREADS) void mhx_user_split_sweep(\n"
          "    const ProblemDesc* P, ChainState S) {\n"
          "  k_split_sweep_body<UserSpec>(P, S);\n}\n"
+         "extern \"C\" __global__ __launch_bounds__(MHX_USER_THREADS) void mhx_user_split_tsweep(\n"
+         "    const ProblemDesc* P, const FnDesc* slices, ChainState S, int n_slices) {\n"
+         "  k_split_tsweep_body<UserSpec>(P, slices, S, n_slices);\n}\n"
          "extern \"C\" __global__ __launch_bounds__(MHX_USER_THREADS) void mhx_user_split_step(\n"
          "    const ProblemDesc* P, ChainState S, RunDesc R, int mode, int plain) {\n"
          "  k_adaptive_body<UserSpec, true>(P, S, R, 1, plain, mode);\n}\n";
@@ -494,13 +497,19 @@ static int build_once(const std::vector<UserExpr>& models, const std::vector<Use
     if (he == hipSuccess)
       he = hipModuleGetFunction(&prog->f_split_step, prog->module, "mhx_user_split_step");
     if (he == hipSuccess)
+      he = hipModuleGetFunction(&prog->f_split_tsweep, prog->module, "mhx_user_split_tsweep");
+    if (he == hipSuccess)
+      he = hipFuncSetAttribute(reinterpret_cast<const void*>(prog->f_split_tsweep),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)fam.lds_bytes);
+    if (he == hipSuccess)
       he = hipFuncSetAttribute(reinterpret_cast<const void*>(prog->f_split_step),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)fam.lds_bytes);
     if (he != hipSuccess) {
       *err = std::string("split-mode module functions: ") + hipGetErrorString(he);
       return -1;
     }
-    if (static_lds(prog->f_split_sweep) != 0 || static_lds(prog->f_split_step) != 0) {
+    if (static_lds(prog->f_split_sweep) != 0 || static_lds(prog->f_split_step) != 0 ||
+        static_lds(prog->f_split_tsweep) != 0) {
       *err = "split-mode module functions have static LDS";
       return -1;
     }
@@ -602,6 +611,14 @@ hipError_t rtc_launch_split_sweep(const UserProgram& p, hipStream_t st, const Pr
   return hipModuleLaunchKernel(p.f_split_sweep, (unsigned)slices, (unsigned)S.n_chains, 1,
                                (unsigned)p.fam->threads, 1, 1, (unsigned)p.fam->sweep_lds_bytes, st,
                                args, nullptr);
+}
+hipError_t rtc_launch_split_tsweep(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                                   const FnDesc* slices, const ChainState& S, int n_slices) {
+  ChainState s = S;
+  void* args[] = {(void*)&P, (void*)&slices, (void*)&s, (void*)&n_slices};
+  return hipModuleLaunchKernel(p.f_split_tsweep, (unsigned)n_slices, grid_for(p, S.n_chains), 1,
+                               (unsigned)p.fam->threads, 1, 1, (unsigned)p.fam->lds_bytes, st, args,
+                               nullptr);
 }
 hipError_t rtc_launch_split_step(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                                  const ChainState& S, const RunDesc& R, int mode, int plain) {

@@ -32,6 +32,7 @@ struct UserProgram {
   hipModule_t module = nullptr;
   hipFunction_t f_logpost = nullptr, f_init = nullptr, f_step = nullptr, f_adaptive = nullptr;
   hipFunction_t f_split_sweep = nullptr, f_split_step = nullptr;  // only with has_split
+  hipFunction_t f_split_tsweep = nullptr;                         // (the tile-sliced sweep)
   bool has_split = false;
   const Family* fam = nullptr;  // the kernel family (workgroup shape) the module was built for
   std::string source, log;
@@ -67,6 +68,8 @@ hipError_t rtc_launch_step_injected(const UserProgram& p, hipStream_t st, const 
                                     unsigned char* accepted);
 hipError_t rtc_launch_split_sweep(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                                   const ChainState& S, int slices);
+hipError_t rtc_launch_split_tsweep(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                                   const FnDesc* slices, const ChainState& S, int n_slices);
 hipError_t rtc_launch_split_step(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                                  const ChainState& S, const RunDesc& R, int mode, int plain);
 hipError_t rtc_launch_adaptive(const UserProgram& p, hipStream_t st, const ProblemDesc* P,

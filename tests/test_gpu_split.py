@@ -82,6 +82,112 @@ def test_split_walks_like_the_batch_kernels(mhx, orc, name, make, lscale):
         e.close()
 
 
+def ts_engine(mhx, spec, chains, ts, **kw):
+    """an engine finalised under MHX_TSPLIT=<ts> (None: the engine's own choice)"""
+    old = {k: os.environ.get(k) for k in ("MHX_TSPLIT", "MHX_SPLIT")}
+    os.environ.pop("MHX_SPLIT", None)
+    if ts is None:
+        os.environ.pop("MHX_TSPLIT", None)
+    else:
+        os.environ["MHX_TSPLIT"] = str(ts)
+        if ts == 0:
+            os.environ["MHX_SPLIT"] = "0"
+    try:
+        e = spec.engine(mhx, chains, **kw)
+        name = e.kernel_name()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return e, name
+
+
+TS_CASES = [   # (..., chains, slices asked for: None = the engine's own choice)
+    ("two_peak", lambda: pb.two_peak(n=30000, seed=3), None, 20, None),
+    ("two_peak_ragged", lambda: pb.two_peak(n=9001, seed=13), None, 9, 4),  # 5 windows, a short last one
+    ("poisson", lambda: pb.poisson_peaks(n=24000, seed=4), 0.002, 11, None),
+    ("global_fit", lambda: pb.global_fit(n_each=7000, n_sets=3, seed=5), None, 16, None),
+]
+
+
+@pytest.mark.parametrize("name,make,lscale,chains,ask", TS_CASES, ids=[c[0] for c in TS_CASES])
+def test_tile_sliced_split_walks_like_the_batch_kernels(mhx, orc, name, make, lscale, chains, ask):
+    """k_split_tsweep: groups of chains on slices of whole windows (the engine's choice from 8
+    chains on, below the batch kernels' range): same proposals, same controller, log-posteriors
+    equal to rounding, deterministic; slices that do not exist (fewer windows than slices in one
+    function of a global fit), a ragged last slice, a last group that is not full"""
+    s = make()
+    n = 900
+    th0 = pb.perturbed(s.theta_star, chains, 0.01, seed=2)
+    l0 = None if lscale is None else np.diag(lscale * np.abs(s.theta_star))
+    batch, nb = ts_engine(mhx, s, chains, 0, seed=9)
+    ts, nt = ts_engine(mhx, s, chains, ask, seed=9)
+    assert "split" not in nb and "tsplit x" in nt, (nb, nt)
+    sb, stb, Lb = walk(batch, th0, n, l0)
+    ss, sts, Ls = walk(ts, th0, n, l0)
+    assert np.array_equal(stb, sts) and (sts == mhx.capi.CHAIN_DONE).all()
+    assert np.array_equal(sb["age"], ss["age"]) and np.array_equal(sb["length"], ss["length"])
+    same = sum(int(np.array_equal(sb["theta"][c], ss["theta"][c])) for c in range(chains))
+    assert same >= chains - 2      # an accept test can differ only inside the rounding band
+    op = s.oracle(orc)
+    for c in range(chains):
+        ref = op.logpost(ss["theta"][c])
+        assert abs(ss["logpost"][c] - ref) <= REL * op.abs_terms(ss["theta"][c]) + 1e-5
+    ts2, _ = ts_engine(mhx, s, chains, ask, seed=9)
+    s2, _, L2 = walk(ts2, th0, n, l0)
+    for k in ("theta", "logpost", "age"):
+        assert np.array_equal(ss[k], s2[k]), k
+    assert np.array_equal(Ls, L2)
+    # ... and with another number of slices the same walk again, to rounding
+    ts3, n3 = ts_engine(mhx, s, chains, 3, seed=9)
+    assert "tsplit x3" in n3 or "tsplit x2" in n3, n3
+    s3, st3, _ = walk(ts3, th0, n, l0)
+    assert np.array_equal(st3, sts)
+    assert sum(int(np.array_equal(s3["theta"][c], ss["theta"][c])) for c in range(chains)) >= chains - 2
+    for e in (batch, ts, ts2, ts3):
+        e.close()
+
+
+def test_tile_sliced_split_with_a_model_compiled_at_run_time(mhx, orc):
+    """the same through hiprtc (mhx_user_split_tsweep): config 2's model given as its closure
+    text, 24 chains"""
+    s = pb.two_peak(n=30000, seed=8)
+    keys, cexpr = mhx.sexpr.lambda_to_expr(
+        "(lambda (x &key b0 b1 a1 mu1 w1 a2 mu2 w2 &allow-other-keys)"
+        " (+ (+ b0 (* b1 x)) (* a1 (exp (- (expt (/ (- x mu1) w1) 2))))"
+        "    (* a2 (exp (- (expt (/ (- x mu2) w2) 2))))))")
+    chains, n = 24, 700
+    th0 = pb.perturbed(s.theta_star, chains, 0.01, seed=4)
+    runs = {}
+    for label, env in (("batch", {"MHX_SPLIT": "0"}), ("tsplit", {})):
+        old = {k: os.environ.get(k) for k in ("MHX_SPLIT", "MHX_TSPLIT")}
+        for k in old:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            e = s.engine(mhx, chains, seed=5)
+            e.set_function_expr(0, cexpr, keys, list(range(8)))
+            name = e.kernel_name()
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+        assert ("tsplit x" in name) == (label == "tsplit") and "rtc[" in name, name
+        runs[label] = walk(e, th0, n)
+        e.close()
+    (sb, stb, _), (ss, sts, _) = runs["batch"], runs["tsplit"]
+    assert np.array_equal(stb, sts) and (sts == mhx.capi.CHAIN_DONE).all()
+    assert np.array_equal(sb["age"], ss["age"])
+    assert sum(int(np.array_equal(sb["theta"][c], ss["theta"][c])) for c in range(chains)) >= chains - 2
+    op = s.oracle(orc)
+    for c in range(chains):
+        ref = op.logpost(ss["theta"][c])
+        assert abs(ss["logpost"][c] - ref) <= REL * op.abs_terms(ss["theta"][c]) + 1e-5
+
+
 def test_split_single_walker_expression_and_many_steps(mhx):
     rng = np.random.default_rng(6)
     n = 60000
@@ -123,12 +229,24 @@ def test_split_single_walker_expression_and_many_steps(mhx):
 def test_split_mode_is_chosen_by_batch_and_dataset_size(mhx):
     s_long = pb.two_peak(n=100000, seed=1)
     s_short = pb.two_peak(n=3000, seed=1)
-    for spec, chains, want in ((s_long, 1, "split x24"), (s_long, 256, "split x4"),
-                               (s_long, 512, "split x2"), (s_long, 1024, None), (s_long, 2048, None),
-                               (s_short, 1, None), (s_short, 64, None)):
+    # one chain's points over many workgroups below 8 chains; from 8 on groups of 8 chains on
+    # slices of whole windows ("tsplit": about 512 workgroups in the sweep launch); the batch
+    # kernels from 256 workgroups on and for short datasets
+    for spec, chains, want in ((s_long, 1, " split x24"), (s_long, 4, " split x24"),
+                               (s_long, 16, "tsplit x49"), (s_long, 256, "tsplit x16"),
+                               (s_long, 512, "tsplit x8"), (s_long, 1024, "tsplit x4"),
+                               (s_long, 2048, None), (s_short, 1, None), (s_short, 64, None)):
         e, name = engine(mhx, spec, chains, None)
         assert (want in name) if want else ("split" not in name), (chains, name)
         e.close()
+    # MHX_TSPLIT=0: the per-chain split mode where it applies
+    os.environ["MHX_TSPLIT"] = "0"
+    try:
+        e, name = engine(mhx, s_long, 256, None)
+        assert " split x4" in name, name
+        e.close()
+    finally:
+        os.environ.pop("MHX_TSPLIT", None)
     # the pooled-covariance mode (multi-GPU bench) stays on the batch kernels
     e, name = engine(mhx, s_long, 8, None, adapt_mode=mhx.capi.ADAPT_POOLED)
     assert "split" not in name
