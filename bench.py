@@ -273,11 +273,23 @@ def main():
         raise SystemExit("--gpus %d under a launcher with WORLD_SIZE=%d" % (n_gpus, world))
     import torch
     dist = None
+    # MHX_BENCH_REHEARSE_LAUNCHER=1: the launcher path on a box with fewer GPUs than ranks (the
+    # builder's has one): ranks share devices, torch.distributed runs on gloo, and the tick's sum
+    # goes through the torch hook on a host buffer (RCCL does not put two ranks on one device).
+    # Everything else - rendezvous, chain ranges, barriers, the reductions of the timing, the line
+    # rank 0 prints - is the code the driver's N-GPU run executes.
+    rehearse = per_rank and os.environ.get("MHX_BENCH_REHEARSE_LAUNCHER", "") not in ("", "0")
+    red_dev = "cpu" if rehearse else "cuda"  # where the small tensors of dist.all_reduce live
     if per_rank:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import lisp_mcmc_amd as mhx
 
     devices = [local_rank] if per_rank else list(range(n_gpus))
@@ -329,7 +341,7 @@ def main():
         uid, why = [None], ""
         if rank == 0:
             try:
-                uid = [mhx.comm_unique_id()]
+                uid = [("failed", "rehearsal: ranks share a device")] if rehearse else [mhx.comm_unique_id()]
             except Exception as ex:
                 uid = [("failed", str(ex))]
         dist.broadcast_object_list(uid, src=0)
@@ -341,11 +353,11 @@ def main():
                 ok, why = False, str(ex)
         else:
             why = uid[0][1]
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=red_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:  # librccl not usable by libmhx somewhere: the torch.distributed hook
             from lisp_mcmc_amd import distributed as mdist
-            e.set_allreduce(mdist.torch_allreduce_hook(dist), device_buffer=True)
+            e.set_allreduce(mdist.torch_allreduce_hook(dist), device_buffer=not rehearse)
             collective = "torch.distributed all_reduce hook (libmhx RCCL unavailable: %s)" % (why or "on another rank")
     # per-chain start: theta* (1 + 0.01 N(0,1)), keyed by GLOBAL chain id (rank r of a launcher
     # run and device r of a one-process run get the same chains)
@@ -411,7 +423,7 @@ def main():
     t1 = time.perf_counter()
     el = t1 - t0
     if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     kts = fleet.timing()
@@ -419,7 +431,7 @@ def main():
     n_disp += kts[0]["launches"]
     chain_steps = fleet.steps() - steps0
     if dist is not None:
-        t = torch.tensor([float(chain_steps)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([float(chain_steps)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total_steps = float(t.item())
     else:

@@ -283,6 +283,38 @@ def test_bench_gpus_2_in_one_process_rehearsed_on_one_gpu(tmp_path):
     assert sum(c.startswith("GroupStart") for c in calls) == 2
 
 
+def test_bench_under_the_launcher_rehearsed_on_one_gpu(tmp_path):
+    """The driver's N > 1 form: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus
+    2 ...`, one rank per GPU.  Rehearsed with MHX_BENCH_REHEARSE_LAUNCHER=1: both ranks on device
+    0, torch.distributed on gloo, the tick's sum through the torch hook - every other line of the
+    per-rank path (rendezvous, chain ranges by rank, barriers, max-over-ranks time, summed steps,
+    rank 0's one JSON line) is what runs on a node.  Two ticks fall into the run (warm-up ends on
+    iteration 200, the timed region on 400)."""
+    import json
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, MHX_BENCH_REHEARSE_LAUNCHER="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MHX_SPLIT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                          str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--chains", "512",
+                          "--steps", "200", "--warmup", "200", "--no-cpu", "--spin-ms", "5"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 200 and d["warmup"] == 200 and d["scaling"] == "weak"
+    assert d["config"]["chains_per_gpu"] == 512 and "one process per GPU" in d["config"]["parallelism"]
+    assert "torch.distributed all_reduce hook" in d["config"]["collective"]
+    # whole-job rate: both ranks' chain-steps over the slower rank's time
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] * 1e-3 / (2 * 512) - 1.0) < 1e-9
+    assert "cpu_baseline" not in d and "value_direct_form" not in d   # (rank 0 at N = 1 only)
+
+
 @pytest.mark.skipif("__import__('torch').cuda.device_count() < 2")
 def test_two_real_gpus_walk_like_two_engines_on_one():
     """(runs only where two GPUs are visible) Group(devices=[0, 1]) through the REAL librccl
