@@ -140,6 +140,13 @@ def test_tile_sliced_split_walks_like_the_batch_kernels(mhx, orc, name, make, ls
     for k in ("theta", "logpost", "age"):
         assert np.array_equal(ss[k], s2[k]), k
     assert np.array_equal(Ls, L2)
+    # plain steps (mhx_many_steps: no controller) go through the same launches
+    lp = np.diag(0.003 * np.abs(s.theta_star))
+    batch.many_steps(60, lp)
+    ts.many_steps(60, lp)
+    pb_, ps_ = batch.state(), ts.state()
+    assert np.array_equal(pb_["age"], ps_["age"]) and (ps_["age"] == ss["age"] + 60).all()
+    assert sum(int(np.array_equal(pb_["theta"][c], ps_["theta"][c])) for c in range(chains)) >= chains - 3
     # ... and with another number of slices the same walk again, to rounding
     ts3, n3 = ts_engine(mhx, s, chains, 3, seed=9)
     assert "tsplit x3" in n3 or "tsplit x2" in n3, n3
