@@ -157,6 +157,29 @@ def test_tile_sliced_split_walks_like_the_batch_kernels(mhx, orc, name, make, ls
         e.close()
 
 
+def test_tile_sliced_split_in_the_16_wave_family(mhx, orc, monkeypatch):
+    """groups of 16 chains on 2048-point tiles (MHX_FAMILY_WPG=16; the engine's own choice below
+    4096 chains is the 8-wave family): the same walk to rounding"""
+    s = pb.two_peak(n=30000, seed=21)
+    chains, n = 40, 500
+    th0 = pb.perturbed(s.theta_star, chains, 0.01, seed=6)
+    res = {}
+    for fam in ("8", "16"):
+        monkeypatch.setenv("MHX_FAMILY_WPG", fam)
+        e, name = ts_engine(mhx, s, chains, None, seed=3)
+        assert name.startswith("w%s/" % fam) and "tsplit x" in name, name
+        res[fam] = walk(e, th0, n)
+        e.close()
+    (s8, st8, _), (s16, st16, _) = res["8"], res["16"]
+    assert np.array_equal(st8, st16) and (st16 == mhx.capi.CHAIN_DONE).all()
+    assert np.array_equal(s8["age"], s16["age"])
+    assert sum(int(np.array_equal(s8["theta"][c], s16["theta"][c])) for c in range(chains)) >= chains - 3
+    op = s.oracle(orc)
+    for c in range(chains):
+        ref = op.logpost(s16["theta"][c])
+        assert abs(s16["logpost"][c] - ref) <= REL * op.abs_terms(s16["theta"][c]) + 1e-5
+
+
 def test_tile_sliced_split_with_a_model_compiled_at_run_time(mhx, orc):
     """the same through hiprtc (mhx_user_split_tsweep): config 2's model given as its closure
     text, 24 chains"""
