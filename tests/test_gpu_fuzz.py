@@ -1,0 +1,51 @@
+"""Differential fuzz: log-posteriors of wildly perturbed parameter vectors - the proposals a walk
+makes from `diag(theta)` in its first iterations: narrow and wide peaks, negative amplitudes and
+widths, peaks outside the data - must equal the oracle's mirror bit for bit (configs 2 and 3's
+kernels: every window variant, seeding class, guarded window and masked loop gets its share)."""
+import numpy as np
+import pytest
+
+import problems as pb
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mhx():
+    import lisp_mcmc_amd
+    return lisp_mcmc_amd
+
+
+def fuzz(mhx, orc, s, chains, scales, seed, **okw):
+    op = s.oracle(orc, **okw)
+    e = s.engine(mhx, chains)
+    rng = np.random.default_rng(seed)
+    bad = []
+    for sc in scales:
+        th = s.theta_star[None, :] * (1.0 + sc * rng.standard_normal((chains, s.d)))
+        got, parts = e.logpost(th, parts=True)
+        for i, t in enumerate(th):
+            ref, rp = op.logpost_mirror(t, parts=True)
+            same = (got[i] == ref or (np.isnan(got[i]) and np.isnan(ref))) and \
+                   (parts[i, 0] == rp[0] or (np.isnan(parts[i, 0]) and np.isnan(rp[0])))
+            if not same:
+                bad.append((sc, i, got[i], ref, parts[i, 0], rp[0]))
+    e.close()
+    return bad
+
+
+@pytest.mark.parametrize("n", [5000, 70000])
+def test_two_peak_normal_fuzz(mhx, orc, n):
+    bad = fuzz(mhx, orc, pb.two_peak(n=n, seed=n), 512, (0.02, 0.1, 0.3, 1.0, 3.0), seed=n + 1)
+    assert not bad, bad[:5]
+
+
+def test_two_peak_cutoff_fuzz(mhx, orc):
+    bad = fuzz(mhx, orc, pb.two_peak(n=20000, seed=4, lik=pb.CUTOFF), 384, (0.05, 0.3, 1.0), seed=9)
+    assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("n", [3000, 50000])
+def test_five_peak_poisson_fuzz(mhx, orc, n):
+    bad = fuzz(mhx, orc, pb.poisson_peaks(n=n, seed=n), 384, (0.02, 0.1, 0.3, 1.0), seed=n + 2)
+    assert not bad, bad[:5]
