@@ -49,3 +49,28 @@ def test_two_peak_cutoff_fuzz(mhx, orc):
 def test_five_peak_poisson_fuzz(mhx, orc, n):
     bad = fuzz(mhx, orc, pb.poisson_peaks(n=n, seed=n), 384, (0.02, 0.1, 0.3, 1.0), seed=n + 2)
     assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("scale", [0.02, 0.1, 0.3])
+def test_global_fit_pseudo_voigt_fuzz_within_tolerance(mhx, orc, scale):
+    """config 4's kernel has no mirror (its reciprocal starts from v_rcp_f64): held to the
+    faithful oracle within the stated 1e-12 sum |term| on perturbed parameter vectors - the fast
+    path (one shared reciprocal, table exps) and, for the wide perturbations, the guarded one"""
+    s = pb.global_fit(n_each=6000, n_sets=4, seed=11)
+    op = s.oracle(orc)
+    chains = 128
+    e = s.engine(mhx, chains)
+    rng = np.random.default_rng(int(scale * 1000))
+    th = s.theta_star[None, :] * (1.0 + scale * rng.standard_normal((chains, s.d)))
+    got, parts = e.logpost(th, parts=True)
+    worst = 0.0
+    for i, t in enumerate(th):
+        ref, rp = op.logpost(t, parts=True)
+        if not np.isfinite(ref):
+            assert not np.isfinite(got[i]), (i, got[i], ref)
+            continue
+        tol = 1e-12 * op.abs_terms(t)
+        assert abs(parts[i, 0] - rp[0]) <= tol, (scale, i, parts[i, 0], rp[0], tol)
+        worst = max(worst, abs(parts[i, 0] - rp[0]) / tol)
+    e.close()
+    assert worst < 1.0
