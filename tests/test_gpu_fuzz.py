@@ -74,3 +74,27 @@ def test_global_fit_pseudo_voigt_fuzz_within_tolerance(mhx, orc, scale):
         worst = max(worst, abs(parts[i, 0] - rp[0]) / tol)
     e.close()
     assert worst < 1.0
+
+
+@pytest.mark.parametrize("npk,n", [(3, 30000), (4, 9000)])
+def test_run_time_specialised_peaks_fuzz(mhx, orc, npk, n):
+    """three and four Gaussian peaks on a linear background: no ahead-of-time kernel, compiled
+    for gfx950 on first use (hiprtc, PeaksModel<2, npk>): the run-time-masked peak loops and the
+    per-peak seeding constants in LDS, against the mirror, every bit"""
+    rng = np.random.default_rng(npk)
+    x = np.linspace(0.0, 1.0, n)
+    sig = rng.uniform(0.05, 0.15, n)
+    th = [0.5, 0.3]
+    for k in range(npk):
+        th += [rng.uniform(0.6, 1.2), (k + 0.6) / (npk + 0.2), rng.uniform(0.03, 0.07)]
+    th = np.array(th)
+    y = pb.model_eval_np(pb.GAUSS, (2, npk), th, x) + sig * rng.standard_normal(n)
+    s = pb.Spec(len(th))
+    lo, hi = np.minimum(th * 0.5, th * 1.5), np.maximum(th * 0.5, th * 1.5)
+    s.add(pb.GAUSS, (2, npk), range(len(th)), x, y, sig, pb.NORMAL, (list(range(len(th))), lo, hi))
+    s.theta_star = th
+    e = s.engine(mhx, 1)
+    assert "rtc[PeaksModel<2, %d, false>" % npk in e.kernel_name(), e.kernel_name()
+    e.close()
+    bad = fuzz(mhx, orc, s, 256, (0.02, 0.1, 0.3, 1.0), seed=npk + 40)
+    assert not bad, bad[:5]
