@@ -508,9 +508,11 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
         // one section per tile in the 8-wave family, one or two in the 16-wave family
         constexpr int NIT = kTilePoints / kWave / P;
 #ifndef MHX_NIN_MASKED
-// unrolled iterations per section of the 4-point (run-time mask) loops: 8 (a whole 2048-point
-// tile) measured 4 % slower than 4 on config 3 (code size)
-#define MHX_NIN_MASKED 4
+// unrolled iterations per section of the 4-point (run-time mask) loops: 8 = a whole 2048-point
+// tile.  (Round 2: 4, 8 measured 4 % slower on config 3 - code size; since the instruction-level
+// pass of round 3 took a third off those loops' code, 8 is 1.9 % faster - 73.2 against 74.6 ms -
+// and 2 is 4 % slower; g23, compiled at run time with 2-point loops: no difference.)
+#define MHX_NIN_MASKED 8
 #endif
         constexpr int kMaxIn = (P == MHX_PPI) ? 8 : MHX_NIN_MASKED;
         constexpr int NIN = NIT > kMaxIn ? kMaxIn : NIT;
