@@ -356,7 +356,7 @@ int choose_split(const mhx_engine* e, const Family& fam, bool capable) {
 // every CU a workgroup of the batch kernels and big enough to fill workgroups of their own:
 // about two workgroups per CU in the sweep launch.  MHX_TSPLIT=0 switches it off (the per-chain
 // split mode or the batch kernels then), MHX_TSPLIT=<n> asks for n slices; MHX_SPLIT=0 means the
-// batch kernels here too.
+// batch kernels here too, MHX_SPLIT=<n> alone the per-chain split mode.
 int choose_tsplit(const mhx_engine* e, const Family& fam, bool capable) {
   if (!capable || e->cfg.adapt_mode == MHX_ADAPT_POOLED) return 0;
   int64_t longest = 0;
@@ -366,8 +366,10 @@ int choose_tsplit(const mhx_engine* e, const Family& fam, bool capable) {
   const int W = fam.waves_per_group;
   const int64_t groups = (C + W - 1) / W;
   int64_t want = 0;
+  // (MHX_SPLIT set: the caller has decided - the batch kernels, or the per-chain split mode)
+  if (getenv("MHX_SPLIT") && !getenv("MHX_TSPLIT")) return 0;
   if (const char* s0 = getenv("MHX_SPLIT"))
-    if (atoi(s0) <= 0) return 0;  // "the batch kernels"
+    if (atoi(s0) <= 0) return 0;
   if (const char* s = getenv("MHX_TSPLIT")) {
     want = atoi(s);
     if (want <= 0) return 0;
