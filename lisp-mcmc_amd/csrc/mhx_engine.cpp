@@ -235,6 +235,7 @@ struct mhx_engine {
   // tile-sliced split mode (k_split_tsweep): split_slices = slices of whole windows per function,
   // ts_table = their FnDescs [K][split_slices] on the device
   bool tsplit = false;
+  int ts_initial = 0;  // slices a run starts with (compact_tsplit may cut finer as chains finish)
   DevBuf<FnDesc> ts_table;
   bool chains_ready = false;
 
@@ -394,6 +395,41 @@ int choose_tsplit(const mhx_engine* e, const Family& fam, bool capable) {
   return want >= 2 ? (int)want : 0;
 }
 
+// The slice table of the tile-sliced split mode: function k, slice s = windows [s per_k,
+// (s + 1) per_k) of its dataset, as a FnDesc of its own (what k_split_tsweep hands to sweep()).
+int build_ts_table(mhx_engine* e, int ts) {
+  std::vector<FnDesc> tab((size_t)e->P.K * ts);
+  for (int k = 0; k < e->P.K; ++k) {
+    const FnDesc& f = e->P.fn[k];
+    const int64_t nwin = (f.n + kPadPoints - 1) / kPadPoints;
+    const int64_t per = (nwin + ts - 1) / ts;
+    for (int sl = 0; sl < ts; ++sl) {
+      FnDesc g = f;
+      const int64_t off = (int64_t)sl * per * kPadPoints;
+      g.lik_const = 0.0;
+      g.solo = 0;
+      if (off >= f.n) {
+        g.n = 0;
+        g.n_tiles = 0;
+      } else {
+        g.n = std::min<int64_t>(per * kPadPoints, f.n - off);
+        g.n_tiles = (g.n + e->fam->tile_points - 1) / e->fam->tile_points;
+        g.x = f.x + off;
+        g.y = f.y + off;
+        if (f.w) g.w = f.w + off;
+        if (f.c) g.c = f.c + off;
+        if (f.txlo) g.txlo = f.txlo + off / kPadPoints;
+        if (f.txhi) g.txhi = f.txhi + off / kPadPoints;
+      }
+      tab[(size_t)k * ts + sl] = g;
+    }
+  }
+  if (e->ts_table.n < tab.size() && e->ts_table.alloc(tab.size(), false) != hipSuccess)
+    return fail(MHX_ENOMEM, "hipMalloc of the slice table failed");
+  HIP_TRY(hipMemcpy(e->ts_table.p, tab.data(), tab.size() * sizeof(FnDesc), hipMemcpyHostToDevice));
+  return MHX_OK;
+}
+
 // Which workgroup shape serves this problem (mhx_types.hpp).  16 chains per workgroup and
 // 2048-point tiles pay off when the datasets are long (>= 4 such tiles) and there are enough
 // chains to give every CU its one workgroup; otherwise 8 chains per workgroup (more, smaller
@@ -547,40 +583,20 @@ int finalize_problem(mhx_engine* e) {
     e->split_slices = e->tsplit ? ts : choose_split(e, *e->fam, capable);
     e->S.split_slots = e->tsplit ? e->split_slices : e->split_slices * e->fam->waves_per_group;
     e->S.split_part = nullptr;
+    e->ts_initial = e->tsplit ? ts : 0;
     if (e->tsplit) {
-      // the slice table: function k, slice s = windows [s per_k, (s + 1) per_k) of its dataset
-      std::vector<FnDesc> tab((size_t)e->P.K * ts);
-      for (int k = 0; k < e->P.K; ++k) {
-        const FnDesc& f = e->P.fn[k];
-        const int64_t nwin = (f.n + kPadPoints - 1) / kPadPoints;
-        const int64_t per = (nwin + ts - 1) / ts;
-        for (int sl = 0; sl < ts; ++sl) {
-          FnDesc g = f;
-          const int64_t off = (int64_t)sl * per * kPadPoints;
-          g.lik_const = 0.0;
-          g.solo = 0;
-          if (off >= f.n) {
-            g.n = 0;
-            g.n_tiles = 0;
-          } else {
-            g.n = std::min<int64_t>(per * kPadPoints, f.n - off);
-            g.n_tiles = (g.n + e->fam->tile_points - 1) / e->fam->tile_points;
-            g.x = f.x + off;
-            g.y = f.y + off;
-            if (f.w) g.w = f.w + off;
-            if (f.c) g.c = f.c + off;
-            if (f.txlo) g.txlo = f.txlo + off / kPadPoints;
-            if (f.txhi) g.txhi = f.txhi + off / kPadPoints;
-          }
-          tab[(size_t)k * ts + sl] = g;
-        }
-      }
-      if (e->ts_table.alloc(tab.size(), false) != hipSuccess)
-        return fail(MHX_ENOMEM, "hipMalloc of the slice table failed");
-      HIP_TRY(hipMemcpy(e->ts_table.p, tab.data(), tab.size() * sizeof(FnDesc), hipMemcpyHostToDevice));
+      const int rc = build_ts_table(e, ts);
+      if (rc != MHX_OK) return rc;
     }
     if (e->split_slices > 0) {
-      const size_t np = (size_t)e->cfg.n_chains * e->P.K * e->S.split_slots;
+      // (tile-sliced: room for the most slices a later re-slicing may take - compact_slots)
+      int64_t nwin_max = 1;
+      for (int k = 0; k < e->P.K; ++k)
+        nwin_max = std::max<int64_t>(nwin_max, (e->P.fn[k].n + kPadPoints - 1) / kPadPoints);
+      const size_t slots_max =
+          e->tsplit ? (size_t)std::max<int64_t>(e->S.split_slots, std::min<int64_t>(nwin_max, 512))
+                    : (size_t)e->S.split_slots;
+      const size_t np = (size_t)e->cfg.n_chains * e->P.K * slots_max;
       if (e->split_part.alloc(np) != hipSuccess)
         return fail(MHX_ENOMEM, "hipMalloc of the split-mode partial sums failed");
       e->S.split_part = e->split_part.p;
@@ -793,9 +809,57 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // adaptation; Philox is keyed by the chain's global id; in the pooled mode the statistics kernels
 // index chains, not slots, and the pooled factor is the same for every chain).  Batch kernels
 // only (split mode has no idle waves).  MHX_NO_COMPACT=1: off.
+// Tile-sliced split mode: the chains still walking are PACKED into as few groups as hold them
+// (a group's workgroups walk their slices whether one of its chains is pending or all eight), and
+// the functions are cut again so that the sweep launch keeps about 512 workgroups.  The partial
+// sums are then grouped by other slices: results to rounding, like everything in the split modes.
+int compact_tsplit(mhx_engine* e, const std::vector<int32_t>& st, int64_t running) {
+  const int64_t W = e->fam->waves_per_group;
+  const int64_t mapped = e->slots_mapped > 0 ? e->slots_mapped : e->cfg.n_chains;
+  if (running <= 0 || running * 4 > mapped * 3) return MHX_OK;
+  const int64_t groups = (running + W - 1) / W;
+  std::vector<int32_t> map((size_t)(groups * W), -1);
+  size_t j = 0;
+  for (size_t c = 0; c < st.size(); ++c)
+    if (st[c] == MHX_CHAIN_RUNNING) map[j++] = (int32_t)c;
+  if (!e->slot_map.p && e->slot_map.alloc((size_t)e->cfg.n_chains + (size_t)W) != hipSuccess)
+    return fail(MHX_ENOMEM, "hipMalloc of the slot map failed");
+  HIP_TRY(hipMemcpy(e->slot_map.p, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  e->S.slot_chain = e->slot_map.p;
+  e->S.n_slots = (int64_t)map.size();
+  e->slots_mapped = running;
+  int64_t nwin = 1;
+  for (int k = 0; k < e->P.K; ++k)
+    nwin = std::max<int64_t>(nwin, (e->P.fn[k].n + kPadPoints - 1) / kPadPoints);
+  const char* forced = getenv("MHX_TSPLIT");
+  const int64_t ts = forced ? e->split_slices
+                            : std::max<int64_t>(e->split_slices,
+                                                std::min<int64_t>(std::min<int64_t>(512 / groups, nwin), 512));
+  if (ts != e->split_slices) {
+    const int rc = build_ts_table(e, (int)ts);
+    if (rc != MHX_OK) return rc;
+    e->split_slices = (int)ts;
+    e->S.split_slots = (int)ts;
+  }
+  drop_split_graph(e);  // (the chain state is an argument frozen into the captured launches)
+  return MHX_OK;
+}
+
+// a new run: every chain walks again, in the slices the problem was finalised with
+int reset_tsplit(mhx_engine* e) {
+  if (!e->tsplit || e->split_slices == e->ts_initial) return MHX_OK;
+  const int rc = build_ts_table(e, e->ts_initial);
+  if (rc != MHX_OK) return rc;
+  e->split_slices = e->ts_initial;
+  e->S.split_slots = e->ts_initial;
+  return MHX_OK;
+}
+
 int compact_slots(mhx_engine* e, const std::vector<int32_t>& st, int64_t running) {
   const char* nc = getenv("MHX_NO_COMPACT");
-  if ((nc && atoi(nc) != 0) || e->split_slices > 0 || !e->fam) return MHX_OK;
+  if ((nc && atoi(nc) != 0) || !e->fam) return MHX_OK;
+  if (e->tsplit) return compact_tsplit(e, st, running);
+  if (e->split_slices > 0) return MHX_OK;
   const int64_t W = e->fam->waves_per_group;
   const int64_t in_use = e->S.slot_chain ? e->S.n_slots : e->cfg.n_chains;
   const int64_t groups = (in_use + W - 1) / W;
@@ -1497,6 +1561,7 @@ static int adaptive_begin_enqueue(mhx_engine* e, const mhx_run_opts* o) {
   e->S.slot_chain = nullptr;  // every chain walks again: slot s is chain s (compact_slots)
   e->S.n_slots = e->cfg.n_chains;
   e->slots_mapped = 0;
+  if ((rc = reset_tsplit(e)) != MHX_OK) return rc;
   if ((rc = deal_initial(e)) != MHX_OK) return rc;
   const int d = e->P.d;
   RunDesc& R = e->R;
@@ -1634,6 +1699,7 @@ static int plain_steps(mhx_engine* e, int64_t n, const double* L, int per_chain_
   e->S.slot_chain = nullptr;
   e->S.n_slots = e->cfg.n_chains;
   e->slots_mapped = 0;
+  if ((rc = reset_tsplit(e)) != MHX_OK) return rc;
   const size_t C = (size_t)e->cfg.n_chains, dd = (size_t)e->P.d * e->P.d;
   if (per_chain_l) {
     HIP_TRY(hipMemcpy(e->L.p, L, C * dd * sizeof(double), hipMemcpyHostToDevice));

@@ -1861,10 +1861,14 @@ __device__ __forceinline__ void k_split_tsweep_body(const ProblemDesc* __restric
   const ProblemDesc& P = *Pp;
   const int w = wave_in_group(), l = lane_id(), d = P.d;
   const int slice = (int)blockIdx.x;
-  const int64_t c = (int64_t)blockIdx.y * kWavesPerGroup + w;
-  const bool valid = c < S.n_chains;
-  const bool active =
-      valid && __builtin_amdgcn_readfirstlane(S.split_pending[valid ? c : 0]) != 0;
+  // wave slot -> chain (ChainState::slot_chain: the chains still walking, packed into groups)
+  const int64_t slot = (int64_t)blockIdx.y * kWavesPerGroup + w;
+  const bool in_range = slot < (S.slot_chain ? S.n_slots : S.n_chains);
+  const int64_t mapped =
+      in_range && S.slot_chain ? (int64_t)__builtin_amdgcn_readfirstlane(S.slot_chain[slot]) : slot;
+  const bool valid = in_range && mapped >= 0;
+  const int64_t c = valid ? mapped : 0;
+  const bool active = valid && __builtin_amdgcn_readfirstlane(S.split_pending[c]) != 0;
   // nothing to judge in this group?  (a flag of the dynamic LDS: __syncthreads_or() keeps a static
   // __shared__ word, and static LDS would sit in front of the math tables - mhx_device.hpp)
   if (active && l == 0) lds.vote[2] = 1;

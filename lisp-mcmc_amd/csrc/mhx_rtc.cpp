@@ -616,7 +616,8 @@ hipError_t rtc_launch_split_tsweep(const UserProgram& p, hipStream_t st, const P
                                    const FnDesc* slices, const ChainState& S, int n_slices) {
   ChainState s = S;
   void* args[] = {(void*)&P, (void*)&slices, (void*)&s, (void*)&n_slices};
-  return hipModuleLaunchKernel(p.f_split_tsweep, (unsigned)n_slices, grid_for(p, S.n_chains), 1,
+  return hipModuleLaunchKernel(p.f_split_tsweep, (unsigned)n_slices,
+                               grid_for(p, S.slot_chain ? S.n_slots : S.n_chains), 1,
                                (unsigned)p.fam->threads, 1, 1, (unsigned)p.fam->lds_bytes, st, args,
                                nullptr);
 }
@@ -625,7 +626,7 @@ hipError_t rtc_launch_split_step(const UserProgram& p, hipStream_t st, const Pro
   ChainState s = S;
   RunDesc r = R;
   void* args[] = {(void*)&P, (void*)&s, (void*)&r, (void*)&mode, (void*)&plain};
-  return hipModuleLaunchKernel(p.f_split_step, grid_for(p, S.n_chains), 1, 1,
+  return hipModuleLaunchKernel(p.f_split_step, grid_for(p, S.slot_chain ? S.n_slots : S.n_chains), 1, 1,
                                (unsigned)p.fam->threads, 1, 1, (unsigned)p.fam->lds_bytes, st, args,
                                nullptr);
 }

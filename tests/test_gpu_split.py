@@ -157,6 +157,53 @@ def test_tile_sliced_split_walks_like_the_batch_kernels(mhx, orc, name, make, ls
         e.close()
 
 
+def test_tile_sliced_split_repacks_the_chains_still_walking(mhx, orc, monkeypatch):
+    """complete walker-adaptive-steps runs end at different loop indices (:prob-settle): between
+    portions of launches the chains still walking are packed into fewer groups and the functions
+    cut into more slices (compact_tsplit).  The sums are then grouped differently - results to
+    rounding - so what is asserted is what a run must deliver either way: every chain done, the
+    same ages as without repacking for the chains whose accept tests never sat in the rounding
+    band, final log-posteriors equal to the oracle's at the final parameters, parameters
+    recovered; and a second run on the same engine starts from the original slicing again."""
+    s = pb.two_peak(n=30000, seed=31)
+    chains, n = 72, 7000
+    th0 = pb.perturbed(s.theta_star, chains, 0.01, seed=8)
+    res = {}
+    for label, nc in (("packed", None), ("fixed", "1")):
+        if nc is None:
+            monkeypatch.delenv("MHX_NO_COMPACT", raising=False)
+        else:
+            monkeypatch.setenv("MHX_NO_COMPACT", nc)
+        e, name = ts_engine(mhx, s, chains, None, seed=17)
+        assert "tsplit x" in name, name
+        e.init_chains(th0)
+        e.adaptive_begin(n, 10.0, 1)
+        left = 1
+        while left:
+            left = e.adaptive_advance(600)     # portions: the engine looks at the states between them
+        st, stat = e.state(), e.chain_status()[0]
+        if label == "packed":                  # ... and once more on the same engine
+            e.init_chains(th0)
+            e.adaptive_begin(n, 10.0, 1)
+            e.adaptive_advance(1 << 40)
+            st2, stat2 = e.state(), e.chain_status()[0]
+            assert (stat2 == mhx.capi.CHAIN_DONE).all()
+            assert np.array_equal(st2["age"] > 0, st["age"] > 0)
+        res[label] = (st, stat)
+        e.close()
+    op = s.oracle(orc)
+    for label, (st, stat) in res.items():
+        assert (stat == mhx.capi.CHAIN_DONE).all(), label
+        assert len(set(st["age"].tolist())) > 3, label          # they did end at different times
+        for c in range(0, chains, 5):
+            ref = op.logpost(st["theta"][c])
+            assert abs(st["logpost"][c] - ref) <= REL * op.abs_terms(st["theta"][c]) + 1e-5, (label, c)
+        rel = np.abs(np.median(st["best_theta"], axis=0) / s.theta_star - 1.0)
+        assert rel.max() < 0.05, (label, rel)
+    same = int((res["packed"][0]["age"] == res["fixed"][0]["age"]).sum())
+    assert same >= chains // 2, same
+
+
 def test_tile_sliced_split_in_the_16_wave_family(mhx, orc, monkeypatch):
     """groups of 16 chains on 2048-point tiles (MHX_FAMILY_WPG=16; the engine's own choice below
     4096 chains is the 8-wave family): the same walk to rounding"""
