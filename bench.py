@@ -398,7 +398,11 @@ def main():
     # profiling pass: about --spin-ms at the rate of the headline workload)
     spin_ms, n_disp = 0.0, 0  # (n_disp: k_adaptive dispatches per GPU so far - tools/profile_summary.py)
     fleet.start(th0, n_adapt, l0)
-    if args.spin_ms > 0:
+    spin = None
+    variant = os.environ.get("MHX_BENCH_SPIN_VARIANT", "2")  # (A/B of the order below; 2 = default)
+
+    def do_spin():
+        nonlocal spin, spin_ms, n_disp
         spin = make(pooled=False)  # (no communicator of its own: the kernel is the same)
         spin.start(th0, n_adapt, l0)
         spin_iters = max(8, min(2000, int(args.spin_ms / 60.0 * 1.6e11 / work)))
@@ -408,11 +412,30 @@ def main():
         t = spin.timing(reset=True)
         spin_ms = max(x["total_ms"] for x in t)
         n_disp += t[0]["launches"]
-        spin.close()
+        if variant == "0":
+            spin.close()
+            spin = None
+
     w_per, w_n = launches_of(args.warmup) if args.warmup > 0 else (0, 0)
-    for _ in range(w_n):
-        fleet.advance(w_per)
-    n_disp += fleet.timing(reset=True)[0]["launches"]
+
+    def do_warmup():
+        nonlocal n_disp
+        for _ in range(w_n):
+            fleet.advance(w_per)
+        n_disp += fleet.timing(reset=True)[0]["launches"]
+
+    # The throw-away fleet is set up BEFORE the walk's warm-up iterations and runs AFTER them,
+    # right in front of the timed region, and it is closed only after the measurement: freeing
+    # its buffers (a dozen hipFree) between spin and walk left the GPU idle long enough to lose
+    # 3-7 % of the clock again (same box, 3.31 against 3.17 ms).
+    if variant == "2":
+        do_warmup()
+        if args.spin_ms > 0:
+            do_spin()
+    else:
+        if args.spin_ms > 0:
+            do_spin()
+        do_warmup()
     per_launch, n_launch = launches_of(args.steps)
     steps0 = fleet.steps()
     sync()
@@ -516,8 +539,9 @@ def main():
                                    " [REHEARSAL: %d engines on %d physical device(s)]"
                                    % (len(devices), len(set(devices)))),
                    **({"collective": collective} if collective else {}),
-                   "clock_spin": ("%.0f ms of the same kernel on a throw-away engine before the walk's "
-                                  "warm-up launch" % spin_ms) if spin_ms else "none",
+                   "clock_spin": ("%.0f ms of the same kernel on a throw-away engine %s" % (
+                       spin_ms, "between the walk's warm-up launch and its timed launch"
+                       if variant == "2" else "before the walk's warm-up launch")) if spin_ms else "none",
                    "kernel": "k_adaptive @ " + fleet.kernel_name()},
         "build": {"id": build_id},
         "roofline": roof,
@@ -577,6 +601,8 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     fleet.close()
+    if spin is not None:
+        spin.close()
     if dist is not None:
         dist.destroy_process_group()
 
