@@ -34,9 +34,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # fp64 vector peak: 256 CUs x 4 SIMDs, one wave64 fp64 instruction per SIMD every 4 cycles,
 # 2.4 GHz max clock, an fma = 2 flop x 64 lanes -> 78.6 TFLOP/s (MI355X_MICROARCH.md: half the
-# 157.3 TFLOP/s fp32 vector peak)
+# 157.3 TFLOP/s fp32 vector peak).  The roofline is stated in what is actually counted - VALU
+# wave-instructions issued per second against 1024 x 2.4e9 / 4 = 614.4 G/s - not in flop: only
+# some of the instructions are fmas.
 N_SIMD, CLOCK_HZ, CYCLES_PER_F64_INSTR = 1024, 2.4e9, 4
 FP64_VALU_PEAK_TFLOPS = N_SIMD * CLOCK_HZ / CYCLES_PER_F64_INSTR * 128 / 1e12
+FP64_ISSUE_PEAK_G = N_SIMD * CLOCK_HZ / CYCLES_PER_F64_INSTR / 1e9  # G wave-instructions / s
 ROUND_TAG = "r03"  # profiles/<tag>_<workload>_s<steps>_w<warmup>_summary.json
 
 
@@ -401,10 +404,15 @@ def main():
     spin = None
     variant = os.environ.get("MHX_BENCH_SPIN_VARIANT", "2")  # (A/B of the order below; 2 = default)
 
-    def do_spin():
-        nonlocal spin, spin_ms, n_disp
+    def spin_setup():
+        nonlocal spin
         spin = make(pooled=False)  # (no communicator of its own: the kernel is the same)
         spin.start(th0, n_adapt, l0)
+
+    def do_spin():
+        nonlocal spin, spin_ms, n_disp
+        if spin is None:
+            spin_setup()
         spin_iters = max(8, min(2000, int(args.spin_ms / 60.0 * 1.6e11 / work)))
         s_per, s_n = launches_of(spin_iters)
         for _ in range(s_n):
@@ -424,11 +432,15 @@ def main():
             fleet.advance(w_per)
         n_disp += fleet.timing(reset=True)[0]["launches"]
 
-    # The throw-away fleet is set up BEFORE the walk's warm-up iterations and runs AFTER them,
-    # right in front of the timed region, and it is closed only after the measurement: freeing
-    # its buffers (a dozen hipFree) between spin and walk left the GPU idle long enough to lose
-    # 3-7 % of the clock again (same box, 3.31 against 3.17 ms).
+    # The throw-away fleet is set up (allocations, copies, its first steps, a hiprtc compile for
+    # c2expr) BEFORE the walk's warm-up iterations and only ADVANCED after them, right in front
+    # of the timed region, and it is closed only after the measurement: freeing its buffers (a
+    # dozen hipFree) between spin and walk left the GPU idle long enough to lose 3-7 % of the
+    # clock again (same box, 3.31 against 3.17 ms).  (Rounds 1-2 had no spin and round 3 put it
+    # in front of the warm-up first: --spin-ms 0 gives the like-for-like figure.)
     if variant == "2":
+        if args.spin_ms > 0:
+            spin_setup()
         do_warmup()
         if args.spin_ms > 0:
             do_spin()
@@ -471,18 +483,19 @@ def main():
     build_id = mhx.capi.lib().mhx_build_id().decode()
     # The roof that binds is fp64 VALU issue, not HBM: the chains of a workgroup share every data
     # tile through LDS and the dataset sits in L2, so HBM traffic is a fraction of a per cent of
-    # the algorithmic bytes.  achieved = VALU wave-instructions per second x 128 (an fma: 2 flop x
-    # 64 lanes), with the instructions per data point MEASURED (SQ_INSTS_VALU of the timed launch
-    # of this same command, rocprofv3 --pmc, committed under profiles/); peak = 1024 SIMDs x
-    # 2.4 GHz / 4 cycles per wave64 fp64 instruction x 128 = 78.6 TFLOP/s (per GPU).
+    # the algorithmic bytes.  achieved = VALU wave-instructions per second, with the instructions
+    # per data point MEASURED (SQ_INSTS_VALU of the timed launch of this same command, rocprofv3
+    # --pmc, committed under profiles/); peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 fp64
+    # instruction = 614.4 G wave-instructions/s per GPU (were every one an fma: 78.6 TFLOP/s).
     prof, prof_name, prof_exact = load_profile(args.workload, args.steps, args.warmup)
-    roof = {"bound": "fp64_valu", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": None, "traffic": None,
+    roof = {"bound": "fp64_valu_issue", "achieved": None, "peak": FP64_ISSUE_PEAK_G,
+            "unit": "G wave-instr/s", "frac": None, "traffic": None,
             "kernel_ms_per_launch": kt["avg_ms"], "launches": kt["launches"],
             "iterations_per_launch": per_launch if not pooled else None,
             "timed_dispatches": list(timed_disp),
             "algorithmic_bytes_per_chain_step": bytes_step, "algorithmic_gbs": alg_gbs,
-            "note": "per GPU; fp64 VALU issue bound: 16 chains share each LDS tile and the dataset is "
+            "note": "per GPU; fp64 VALU ISSUE bound (wave64 fp64 instructions issued / s against 1024 SIMDs x "
+                    "2.4 GHz / 4 cycles; not a flop rate): 16 chains share each LDS tile and the dataset is "
                     "L2 resident, so HBM (hbm_gbs, hbm_frac) does not bind; algorithmic_gbs = the "
                     "SURVEY 8d bytes per chain-step x chain-steps / kernel time, for reference only"}
     if n_gpus > 1 and not per_rank:
@@ -505,8 +518,9 @@ def main():
                                        "" if not stale else
                                        " -- STALE: measured on build %s, this is %s" % (prof_build, build_id)))
             roof["instr_source_stale"] = stale
-            roof["achieved"] = instr * 128.0 / kernel_s / 1e12
-            roof["frac"] = roof["achieved"] / FP64_VALU_PEAK_TFLOPS
+            roof["achieved"] = instr / kernel_s / 1e9
+            roof["frac"] = roof["achieved"] / FP64_ISSUE_PEAK_G
+            roof["tflops_if_every_instruction_were_an_fma"] = instr * 128.0 / kernel_s / 1e12
             hbm_per_step = (prof["hbm_read_bytes"] + prof["hbm_write_bytes"]) / prof_steps
             # HBM bytes per launch: FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024
             # of the profiled launch, scaled by chain-steps

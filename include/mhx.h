@@ -200,9 +200,26 @@ int mhx_set_bounds(mhx_engine* e, int k, const int32_t* idx, const double* lo,
  * theta[param_index[j]]), numeric literals, + - * / ?: < <= > >= == != && || !, and the
  * functions exp log sqrt sin cos tan atan tanh abs pow min max.  It is compiled for gfx950
  * with hiprtc into the same fused kernels when the problem is finalised (first
- * mhx_init_chains / mhx_logpost), and evaluated without contraction. */
+ * mhx_init_chains / mhx_logpost), and evaluated without contraction.
+ * A body that IS one of the enumerated models - a polynomial background c0 + c1 x + ... plus
+ * Gaussian peaks a * exp(-ipow((x - mu) / w, 2)) or Lorentzian peaks a / (1 + ipow((x - mu) / w,
+ * 2)) over distinct parameters (pow(u, 2.0), u * u and -1 * S are understood; csrc/mhx_expr.cpp) -
+ * is recognised here, below the ABI, and runs as MHX_MODEL_POLY / _GAUSS_PEAKS / _LORENTZ_PEAKS
+ * with the gather map permuted into that model's order: the same function through the peak
+ * kernels' fused arithmetic (a few ulp per point from the text's own rounding, inside the path's
+ * tolerance), with their per-window peak skipping and uniform-grid recurrence - the lambda a
+ * Lisp host hands to walker-create gets the kernels of BASELINE's config 2 without knowing
+ * them.  A function whose likelihood is MHX_LIK_EXPR always stays an expression. */
 int mhx_set_function_expr(mhx_engine* e, int k, const char* expr, const char* const* param_names,
                           const int32_t* param_index, int n_index);
+/* on = 0: every expression of this engine is compiled exactly as written (default: on). */
+int mhx_set_expr_recognition(mhx_engine* e, int on);
+/* What mhx_set_function_expr makes of `expr` - needs no engine and no device (hosts' logs, tests):
+ * *model = the MHX_MODEL_* that serves it (MHX_MODEL_EXPR: compiled as written), shape[2] its
+ * {nbg, npk}, order[j] = which of param_names is local parameter j of that model (*n_order
+ * entries, at most n_names; 0 for MHX_MODEL_EXPR).  shape, order, n_order may be NULL. */
+int mhx_expr_classify(const char* expr, const char* const* param_names, int n_names,
+                      int32_t* model, int32_t* shape, int32_t* order, int32_t* n_order);
 /* Body of function k's prior-bounds-let prior (M:366-369) as an expression over
  * `bounds_total` (the sum of the block set by mhx_set_bounds) and the identifiers in `names`
  * (names[i] = theta[index[i]]), e.g. NV's "bounds_total + (mu1 > mu2 ? -1e9 : 0.0)". */
@@ -300,6 +317,7 @@ int mhx_group_set_bounds(mhx_group* g, int k, const int32_t* idx, const double* 
 int mhx_group_set_function_expr(mhx_group* g, int k, const char* expr,
                                 const char* const* param_names, const int32_t* param_index,
                                 int n_index);
+int mhx_group_set_expr_recognition(mhx_group* g, int on);
 int mhx_group_set_prior_expr(mhx_group* g, int k, const char* expr, const char* const* names,
                              const int32_t* index, int n);
 int mhx_group_set_likelihood_expr(mhx_group* g, int k, const char* expr);

@@ -54,6 +54,8 @@ SIGNATURES = {
     "mhx_set_bounds": (C.c_int, [C.c_void_p, C.c_int, i32p, f64p, f64p, C.c_int]),
     "mhx_set_function_expr": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_char_p),
                                         i32p, C.c_int]),
+    "mhx_set_expr_recognition": (C.c_int, [C.c_void_p, C.c_int]),
+    "mhx_expr_classify": (C.c_int, [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, i32p, i32p, i32p, i32p]),
     "mhx_set_prior_expr": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_char_p),
                                      i32p, C.c_int]),
     "mhx_set_likelihood_expr": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p]),
@@ -97,6 +99,7 @@ SIGNATURES = {
     "mhx_group_set_bounds": (C.c_int, [C.c_void_p, C.c_int, i32p, f64p, f64p, C.c_int]),
     "mhx_group_set_function_expr": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p,
                                               C.POINTER(C.c_char_p), i32p, C.c_int]),
+    "mhx_group_set_expr_recognition": (C.c_int, [C.c_void_p, C.c_int]),
     "mhx_group_set_prior_expr": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p,
                                            C.POINTER(C.c_char_p), i32p, C.c_int]),
     "mhx_group_set_likelihood_expr": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p]),

@@ -110,7 +110,9 @@ struct Rccl {
 // (tools/debug/rccl_exit_abort.py, round 3).  So the flag is kept local, nothing of RCCL's is
 // ever visible to anybody but this file's dlsym calls, and one test keeps a process with RCCL,
 // hiprtc and torch at exit status 0 (tests/test_gpu_rccl_stub.py).
-// MHX_RCCL_DLOPEN_GLOBAL=1 restores the old flags - for that debug script only.
+// MHX_RCCL_DLOPEN_GLOBAL=1 restores the old flags - for that debug script only, and only in a
+// library built with -DMHX_DEBUG_HOOKS (tests/hooks/libmhx_hooks.so; the release library has
+// neither of the two test switches).
 std::string g_rccl_why;  // why rccl().ok is false
 Rccl& rccl() {
   static Rccl r;
@@ -123,9 +125,13 @@ Rccl& rccl() {
   // that instance
   const char* names[] = {getenv("MHX_RCCL_LIBRARY"), "librccl.so.1", "librccl.so",
                          "/opt/rocm/lib/librccl.so"};
+#ifdef MHX_DEBUG_HOOKS
   const char* dg = getenv("MHX_RCCL_DLOPEN_GLOBAL");
   const int flags = (dg && atoi(dg) != 0) ? (RTLD_NOW | RTLD_GLOBAL | RTLD_NODELETE)
                                            : (RTLD_NOW | RTLD_LOCAL);
+#else
+  const int flags = RTLD_NOW | RTLD_LOCAL;
+#endif
   const char* opened = nullptr;
   for (const char* n : names) {
     if (!n || !*n) continue;
@@ -203,6 +209,8 @@ struct mhx_engine {
   DevBuf<ProblemDesc> dP;
   bool problem_dirty = true;
   UserExpr fn_expr[MHX_MAX_FUNCTIONS];     // MHX_MODEL_EXPR bodies
+  RecognisedModel fn_recog[MHX_MAX_FUNCTIONS];  // ... and what they are (mhx_expr.cpp)
+  bool recognise = true;                   // mhx_set_expr_recognition
   UserExpr prior_expr[MHX_MAX_FUNCTIONS];  // prior-bounds-let bodies
   std::string lik_expr[MHX_MAX_FUNCTIONS]; // create-log-liklihood-function bodies (validated)
   std::shared_ptr<UserProgram> user_prog;  // run-time compiled kernels (shared, rtc_get)
@@ -236,6 +244,11 @@ struct mhx_engine {
   // ts_table = their FnDescs [K][split_slices] on the device
   bool tsplit = false;
   int ts_initial = 0;  // slices a run starts with (compact_tsplit may cut finer as chains finish)
+  // iterations the split modes have queued since the run began.  The tile-sliced mode repacks
+  // only where this count is a multiple of the portion length: when and how the sums are
+  // regrouped is then a function of the walk, not of how the host chunks its advance calls
+  int64_t split_iter = 0;
+  bool ts_repack_due = false;
   DevBuf<FnDesc> ts_table;
   bool chains_ready = false;
 
@@ -449,6 +462,10 @@ const Family& choose_family(const mhx_engine* e) {
 int finalize_problem(mhx_engine* e) {
   if (!e->problem_dirty) return MHX_OK;
   drop_split_graph(e);
+  // a new problem may run in another mode and family: slot s is chain s until the next deal
+  e->S.slot_chain = nullptr;
+  e->S.n_slots = e->cfg.n_chains;
+  e->slots_mapped = 0;
   for (int k = 0; k < e->P.K; ++k) {
     if (!e->fn_set[k]) return fail(MHX_ESTATE, "function %d was never set (mhx_set_function)", k);
     if (!e->data[k].set) return fail(MHX_ESTATE, "dataset %d was never set (mhx_set_dataset)", k);
@@ -494,10 +511,34 @@ int finalize_problem(mhx_engine* e) {
   const char* nts = getenv("MHX_NO_TILE_SKIP");
   const int tile_skip = (nts && atoi(nts) != 0) ? 0 : 1;
   bool any_expr = false;
+  // MHX_NO_RECOGNISE=1: every expression compiled as written (A/B runs; bench.py --workload c2expr)
+  const char* nrec = getenv("MHX_NO_RECOGNISE");
+  const bool recognise = e->recognise && !(nrec && atoi(nrec) != 0);
   for (int k = 0; k < e->P.K; ++k) {
     FnDesc& f = e->P.fn[k];
     f.user_slot = f.prior_slot = -1;
     f.tile_skip = tile_skip;
+    if (!e->fn_expr[k].expr.empty()) {
+      // A function given as an expression: a body that IS polynomial background + Gaussian /
+      // Lorentzian peaks runs as that enumerated model (same gather map, permuted into the
+      // model's order), unless its likelihood is an expression too (which reads `model` from
+      // an expression model) or recognition is off.  Decided here, not in
+      // mhx_set_function_expr: the dataset's likelihood may be set before or after.
+      const UserExpr& u = e->fn_expr[k];
+      const RecognisedModel& r = e->fn_recog[k];
+      if (recognise && r.model >= 0 && f.lik != MHX_LIK_EXPR) {
+        f.model = r.model;
+        f.n_idx = (int)r.order.size();
+        for (int j = 0; j < f.n_idx; ++j) f.idx[j] = u.index[(size_t)r.order[(size_t)j]];
+        f.shape[0] = r.shape[0];
+        f.shape[1] = r.shape[1];
+      } else {
+        f.model = MHX_MODEL_EXPR;
+        f.n_idx = (int)u.index.size();
+        for (int j = 0; j < f.n_idx; ++j) f.idx[j] = u.index[(size_t)j];
+        f.shape[0] = f.shape[1] = 0;
+      }
+    }
     {  // MHX_NO_YW=1: the shared-tile layout with x for every step (A/B runs; same bits either way)
       const char* ny = getenv("MHX_NO_YW");
       f.no_yw = (ny && atoi(ny) != 0) ? 1 : 0;
@@ -796,6 +837,23 @@ int ensure_stage(mhx_engine* e, size_t bytes) {
 }
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// The slot -> chain map on the device (ChainState::slot_chain).  Grown whenever a deal needs more
+// entries than it holds: which of compact_tsplit / compact_slots / deal_initial runs first depends
+// on the problem the engine was finalised for, and the three need different lengths.
+int put_slot_map(mhx_engine* e, const std::vector<int32_t>& map) {
+  if (e->slot_map.n < map.size()) {
+    HIP_TRY(hipStreamSynchronize(e->stream));  // (nobody reads the old map any more)
+    drop_split_graph(e);                       // (its address is frozen into captured launches)
+    e->S.slot_chain = nullptr;
+    if (e->slot_map.alloc(map.size() + 64, false) != hipSuccess)
+      return fail(MHX_ENOMEM, "hipMalloc of the slot map (%zu entries) failed", map.size());
+  }
+  HIP_TRY(hipMemcpy(e->slot_map.p, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  e->S.slot_chain = e->slot_map.p;
+  e->S.n_slots = (int64_t)map.size();
+  return MHX_OK;
+}
+
 // Chains that have finished give up their wave slots - where that pays.  In a long run of many
 // chains the walks end at very different loop indices (:prob-settle), and a workgroup whose
 // chains are mostly done carries idle waves through every tile of every sweep until its last
@@ -822,11 +880,10 @@ int compact_tsplit(mhx_engine* e, const std::vector<int32_t>& st, int64_t runnin
   size_t j = 0;
   for (size_t c = 0; c < st.size(); ++c)
     if (st[c] == MHX_CHAIN_RUNNING) map[j++] = (int32_t)c;
-  if (!e->slot_map.p && e->slot_map.alloc((size_t)e->cfg.n_chains + (size_t)W) != hipSuccess)
-    return fail(MHX_ENOMEM, "hipMalloc of the slot map failed");
-  HIP_TRY(hipMemcpy(e->slot_map.p, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  e->S.slot_chain = e->slot_map.p;
-  e->S.n_slots = (int64_t)map.size();
+  {
+    const int rc = put_slot_map(e, map);
+    if (rc != MHX_OK) return rc;
+  }
   e->slots_mapped = running;
   int64_t nwin = 1;
   for (int k = 0; k < e->P.K; ++k)
@@ -858,7 +915,11 @@ int reset_tsplit(mhx_engine* e) {
 int compact_slots(mhx_engine* e, const std::vector<int32_t>& st, int64_t running) {
   const char* nc = getenv("MHX_NO_COMPACT");
   if ((nc && atoi(nc) != 0) || !e->fam) return MHX_OK;
-  if (e->tsplit) return compact_tsplit(e, st, running);
+  if (e->tsplit) {
+    if (!e->ts_repack_due) return MHX_OK;
+    e->ts_repack_due = false;
+    return compact_tsplit(e, st, running);
+  }
   if (e->split_slices > 0) return MHX_OK;
   const int64_t W = e->fam->waves_per_group;
   const int64_t in_use = e->S.slot_chain ? e->S.n_slots : e->cfg.n_chains;
@@ -883,12 +944,8 @@ int compact_slots(mhx_engine* e, const std::vector<int32_t>& st, int64_t running
       map[(size_t)((j % target) * W + j / target)] = (int32_t)c;
       ++j;
     }
-  if (!e->slot_map.p &&
-      e->slot_map.alloc((size_t)(cus * 2 * W) + (size_t)e->cfg.n_chains + (size_t)W) != hipSuccess)
-    return fail(MHX_ENOMEM, "hipMalloc of the slot map failed");
-  HIP_TRY(hipMemcpy(e->slot_map.p, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  e->S.slot_chain = e->slot_map.p;
-  e->S.n_slots = (int64_t)map.size();
+  const int rc = put_slot_map(e, map);
+  if (rc != MHX_OK) return rc;
   e->slots_mapped = running;
   return MHX_OK;
 }
@@ -912,11 +969,8 @@ int deal_initial(mhx_engine* e) {
   if (target <= groups || C <= W) return MHX_OK;
   std::vector<int32_t> map((size_t)(target * W), -1);
   for (int64_t c = 0; c < C; ++c) map[(size_t)((c % target) * W + c / target)] = (int32_t)c;
-  if (!e->slot_map.p && e->slot_map.alloc((size_t)(cus * 2 * W) + (size_t)C + (size_t)W) != hipSuccess)
-    return fail(MHX_ENOMEM, "hipMalloc of the slot map failed");
-  HIP_TRY(hipMemcpy(e->slot_map.p, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  e->S.slot_chain = e->slot_map.p;
-  e->S.n_slots = (int64_t)map.size();
+  const int rc = put_slot_map(e, map);
+  if (rc != MHX_OK) return rc;
   e->slots_mapped = C;
   return MHX_OK;
 }
@@ -1001,8 +1055,17 @@ int launch_steps_enqueue(mhx_engine* e, int64_t iters, int plain) {
     // drives the iterations, so they go out in portions with a look at the chain states between
     // them (the caller may ask for 2^40 iterations meaning "until done").
     int64_t left = iters;
+    const int64_t portion = std::max<int64_t>(e->split_portion, 16);
+    if (e->ts_repack_due) {  // the last launch ended on a portion boundary: look at the chains now
+      int64_t running = 0;
+      HIP_TRY(hipStreamSynchronize(e->stream));
+      const int rc = count_running(e, &running);
+      if (rc != MHX_OK) return rc;
+      HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    }
     while (left > 0) {
-      const int64_t now = std::min<int64_t>(left, std::max<int64_t>(e->split_portion, 16));
+      // (portions end where split_iter is a multiple of their length, whatever the caller asked for)
+      const int64_t now = std::min<int64_t>(left, portion - e->split_iter % portion);
       auto issue = [&](int64_t count) -> hipError_t {
         hipError_t he = do_split_step(e, 0, plain);
         for (int64_t it = 0; it < count && he == hipSuccess; ++it) {
@@ -1041,6 +1104,8 @@ int launch_steps_enqueue(mhx_engine* e, int64_t iters, int plain) {
       if (!done) HIP_TRY(issue(now));
       e->launches += 2 * (uint64_t)now + 1;
       left -= now;
+      e->split_iter += now;
+      e->ts_repack_due = e->tsplit && e->split_iter % portion == 0;
       if (left > 0) {
         int64_t running = 0;
         HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1147,7 +1212,11 @@ int mhx_version(void) { return MHX_VERSION; }
 #ifndef MHX_SOURCE_ID
 #define MHX_SOURCE_ID "unknown"
 #endif
+#ifdef MHX_DEBUG_HOOKS
+const char* mhx_build_id(void) { return "csrc:" MHX_SOURCE_ID "+hooks"; }
+#else
 const char* mhx_build_id(void) { return "csrc:" MHX_SOURCE_ID; }
+#endif
 const char* mhx_last_error(void) { return g_err.c_str(); }
 
 int mhx_device_count(int* count) {
@@ -1259,6 +1328,7 @@ int mhx_set_function(mhx_engine* e, int k, int model_id, const int32_t* shape, i
   }
   f.model = model_id;
   e->fn_expr[k] = UserExpr();
+  e->fn_recog[k] = RecognisedModel();
   f.n_idx = n_index;
   for (int i = 0; i < 4; ++i) f.shape[i] = i < n_shape ? shape[i] : 0;
   e->fn_set[k] = true;
@@ -1404,7 +1474,41 @@ int mhx_set_function_expr(mhx_engine* e, int k, const char* expr, const char* co
   for (int j = 0; j < n_index; ++j) f.idx[j] = param_index[j];
   for (int i = 0; i < 4; ++i) f.shape[i] = 0;
   e->fn_expr[k] = u;
+  (void)rtc_recognise(expr, u.names, &e->fn_recog[k]);  // which kernels: finalize_problem
   e->fn_set[k] = true;
+  e->problem_dirty = true;
+  return MHX_OK;
+}
+
+int mhx_expr_classify(const char* expr, const char* const* param_names, int n_names,
+                      int32_t* model, int32_t* shape, int32_t* order, int32_t* n_order) {
+  if (!expr || !model) return fail(MHX_EINVAL, "expr/model is NULL");
+  if (n_names < 0 || n_names > MHX_MAX_FN_PARAMS || (n_names > 0 && !param_names))
+    return fail(MHX_EINVAL, "n_names must be in [0,%d]", MHX_MAX_FN_PARAMS);
+  std::vector<std::string> names;
+  for (int j = 0; j < n_names; ++j) {
+    if (!valid_ident(param_names[j]))
+      return fail(MHX_EINVAL, "parameter name %d is not an identifier (or is x / bounds_total)", j);
+    names.push_back(param_names[j]);
+  }
+  std::string out, err;
+  if (rtc_prepare_expr(expr, names, "x", &out, &err) != 0) return fail(MHX_EINVAL, "%s", err.c_str());
+  RecognisedModel r;
+  (void)rtc_recognise(expr, names, &r);
+  *model = r.model >= 0 ? r.model : MHX_MODEL_EXPR;
+  if (shape) {
+    shape[0] = r.shape[0];
+    shape[1] = r.shape[1];
+  }
+  if (n_order) *n_order = (int32_t)r.order.size();
+  if (order)
+    for (size_t j = 0; j < r.order.size(); ++j) order[j] = r.order[j];
+  return MHX_OK;
+}
+
+int mhx_set_expr_recognition(mhx_engine* e, int on) {
+  if (!e) return fail(MHX_EINVAL, "engine is NULL");
+  e->recognise = on != 0;
   e->problem_dirty = true;
   return MHX_OK;
 }
@@ -1561,6 +1665,8 @@ static int adaptive_begin_enqueue(mhx_engine* e, const mhx_run_opts* o) {
   e->S.slot_chain = nullptr;  // every chain walks again: slot s is chain s (compact_slots)
   e->S.n_slots = e->cfg.n_chains;
   e->slots_mapped = 0;
+  e->split_iter = 0;
+  e->ts_repack_due = false;
   if ((rc = reset_tsplit(e)) != MHX_OK) return rc;
   if ((rc = deal_initial(e)) != MHX_OK) return rc;
   const int d = e->P.d;
@@ -1621,6 +1727,10 @@ static int run_failed(mhx_engine* e, int rc) {
 int mhx_adaptive_advance(mhx_engine* e, int64_t max_iters, int64_t* n_running) {
   if (!e) return fail(MHX_EINVAL, "engine is NULL");
   if (!e->run_ready) return fail(MHX_ESTATE, "mhx_adaptive_begin has not been called");
+  if (e->problem_dirty) {
+    e->run_ready = false;
+    return fail(MHX_ESTATE, "the problem was changed after mhx_adaptive_begin: begin again");
+  }
   if (max_iters < 0) return fail(MHX_EINVAL, "max_iters < 0");
   int rc = use_device(e);
   if (rc != MHX_OK) return rc;
@@ -1699,6 +1809,8 @@ static int plain_steps(mhx_engine* e, int64_t n, const double* L, int per_chain_
   e->S.slot_chain = nullptr;
   e->S.n_slots = e->cfg.n_chains;
   e->slots_mapped = 0;
+  e->split_iter = 0;
+  e->ts_repack_due = false;
   if ((rc = reset_tsplit(e)) != MHX_OK) return rc;
   const size_t C = (size_t)e->cfg.n_chains, dd = (size_t)e->P.d * e->P.d;
   if (per_chain_l) {
@@ -2100,7 +2212,7 @@ int group_pool_tick(mhx_group* g) {
     HIP_TRY(hipSetDevice(e->device));
     if ((rc = pool_enqueue_stats(e)) != MHX_OK) return rc;
   }
-  if (g->eng.size() > 1) {
+  if (g->eng.size() > 1 || g->rccl_comms) {
     if (g->rccl_comms) {
       // one collective per device, issued by this one thread: inside ncclGroupStart/End, each
       // call with ITS device current.  Whatever fails in between, the group is closed again
@@ -2179,12 +2291,20 @@ int mhx_group_create(const mhx_config* cfg, const int32_t* devices, int n_device
     g->first.push_back(first);
     g->count.push_back(count);
   }
-  // MHX_GROUP_FORCE_RCCL=1 (tests): engines that share a device take the communicator branch
-  // too - only a stand-in librccl accepts that (tests/stub_rccl); the real one wants one device
-  // per rank, which is why such groups otherwise sum through the host (group_pool_sum_local)
+  // MHX_GROUP_FORCE_RCCL=1 (tests, -DMHX_DEBUG_HOOKS builds only): engines that share a device
+  // take the communicator branch too - only a stand-in librccl accepts that (tests/stub_rccl);
+  // the real one wants one device per rank, which is why such groups otherwise sum through the
+  // host (group_pool_sum_local) - and so does a group of ONE device, which the real librccl
+  // does accept: ncclCommInitAll of one communicator, ncclGroupStart / ncclAllReduce /
+  // ncclGroupEnd per tick, the calls a node with several GPUs makes, on the one GPU of a test box
+#ifdef MHX_DEBUG_HOOKS
   const char* fr = getenv("MHX_GROUP_FORCE_RCCL");
   const bool force_rccl = fr && atoi(fr) != 0;
-  if (n_devices > 1 && cfg->adapt_mode == MHX_ADAPT_POOLED && (distinct || force_rccl)) {
+#else
+  const bool force_rccl = false;
+#endif
+  if ((n_devices > 1 || force_rccl) && cfg->adapt_mode == MHX_ADAPT_POOLED &&
+      (distinct || force_rccl)) {
     Rccl& r = rccl();
     if (!r.ok) return group_fail_cleanup(g, fail(MHX_ECOMM, "RCCL unavailable: %s", g_rccl_why.c_str()));
     std::vector<nccl_comm_t> comms((size_t)n_devices, nullptr);
@@ -2252,6 +2372,9 @@ int mhx_group_set_function_expr(mhx_group* g, int k, const char* expr,
                                 const char* const* param_names, const int32_t* param_index,
                                 int n_index) {
   MHX_GROUP_EACH(mhx_set_function_expr(e, k, expr, param_names, param_index, n_index));
+}
+int mhx_group_set_expr_recognition(mhx_group* g, int on) {
+  MHX_GROUP_EACH(mhx_set_expr_recognition(e, on));
 }
 int mhx_group_set_prior_expr(mhx_group* g, int k, const char* expr, const char* const* names,
                              const int32_t* index, int n) {

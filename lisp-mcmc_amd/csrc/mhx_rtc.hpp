@@ -46,6 +46,18 @@ struct UserProgram {
 int rtc_prepare_expr(const std::string& expr, const std::vector<std::string>& names,
                      const char* extra, std::string* out, std::string* err);
 
+// What an expression IS (mhx_expr.cpp): a polynomial background plus Gaussian or Lorentzian peaks
+// over distinct parameters is served by the enumerated model's kernels.  `expr` is the text as
+// the caller gave it, `names` its parameter names.  order[j] = which of `names` is local
+// parameter j of the enumerated model (bg_0 .., then A, mu, w per peak).
+struct RecognisedModel {
+  int model = -1;  // MHX_MODEL_POLY / _GAUSS_PEAKS / _LORENTZ_PEAKS, -1: not of the shape
+  int shape[2] = {0, 0};
+  std::vector<int> order;
+};
+bool rtc_recognise(const std::string& expr, const std::vector<std::string>& names,
+                   RecognisedModel* out);
+
 // models[slot] / priors[slot] -> compiled module.  builtin_fallback: the problem also has
 // functions with ahead-of-time models, so the generic dispatcher must be part of the kernels.
 // Returns 0 or fills *err.

@@ -48,6 +48,12 @@ class Engine:
         capi.check(capi.lib().mhx_set_function_expr(self._h, k, expr.encode(), self._names(names),
                                                     ixp, len(ix)))
 
+    def set_expr_recognition(self, on):
+        """on=False: every expression of this engine is compiled exactly as written (libmhx
+        otherwise serves polynomial + Gaussian / Lorentzian peak bodies with the enumerated
+        models' kernels: include/mhx.h, mhx_set_function_expr)"""
+        capi.check(capi.lib().mhx_set_expr_recognition(self._h, 1 if on else 0))
+
     def set_prior_expr(self, k, expr, names, index):
         """body of function k's prior over bounds_total and `names` (global parameter indices)"""
         ix, ixp = capi.as_i32(list(index))

@@ -63,6 +63,10 @@ library, or without a gfx950 device, walker-create signals MHX-ERROR."
   (e :pointer) (k :int) (idx :pointer) (lo :pointer) (hi :pointer) (n :int))
 (cffi:defcfun ("mhx_set_function_expr" %mhx-set-function-expr) :int
   (e :pointer) (k :int) (expr :string) (param-names :pointer) (param-index :pointer) (n-index :int))
+(cffi:defcfun ("mhx_set_expr_recognition" %mhx-set-expr-recognition) :int (e :pointer) (on :int))
+(cffi:defcfun ("mhx_expr_classify" %mhx-expr-classify) :int
+  (expr :string) (param-names :pointer) (n-names :int) (model :pointer) (shape :pointer)
+  (order :pointer) (n-order :pointer))
 (cffi:defcfun ("mhx_set_prior_expr" %mhx-set-prior-expr) :int
   (e :pointer) (k :int) (expr :string) (names :pointer) (index :pointer) (n :int))
 (cffi:defcfun ("mhx_set_likelihood_expr" %mhx-set-likelihood-expr) :int
@@ -137,6 +141,8 @@ library, or without a gfx950 device, walker-create signals MHX-ERROR."
   (g :pointer) (k :int) (idx :pointer) (lo :pointer) (hi :pointer) (n :int))
 (cffi:defcfun ("mhx_group_set_function_expr" %mhx-group-set-function-expr) :int
   (g :pointer) (k :int) (expr :string) (param-names :pointer) (param-index :pointer) (n-index :int))
+(cffi:defcfun ("mhx_group_set_expr_recognition" %mhx-group-set-expr-recognition) :int
+  (g :pointer) (on :int))
 (cffi:defcfun ("mhx_group_set_prior_expr" %mhx-group-set-prior-expr) :int
   (g :pointer) (k :int) (expr :string) (names :pointer) (index :pointer) (n :int))
 (cffi:defcfun ("mhx_group_set_likelihood_expr" %mhx-group-set-likelihood-expr) :int

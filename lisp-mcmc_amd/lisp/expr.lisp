@@ -1,7 +1,9 @@
 ;;;; expr.lisp -- reference-style closures and prior-bounds-let bodies as device expressions.
 ;;; (expr-model '(lambda (x &key m b &allow-other-keys) (+ b (* m x)))) walks the quoted form
 ;;; and produces the C-syntax expression mhx_set_function_expr takes (include/mhx.h); libmhx
-;;; compiles it for gfx950 with hiprtc into the same fused kernels.  The walk mirrors
+;;; compiles it for gfx950 with hiprtc into the same fused kernels - or, when the body IS a
+;;; polynomial background plus Gaussian / Lorentzian peaks, serves it with that enumerated model's
+;;; kernels (recognised below the C ABI: csrc/mhx_expr.cpp; nothing to do here).  The walk mirrors
 ;;; lisp-mcmc_amd/sexpr.py, which is what the test-suite exercises (no Lisp implementation
 ;;; exists in the build environment).
 (in-package #:mcmc-fitting-amd)

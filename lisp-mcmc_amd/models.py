@@ -21,27 +21,43 @@ class Model:
         return "Model(%d, %r, %r)" % (self.model_id, self.keys, self.shape)
 
 
-def lisp(lambda_text, recognise=True):
+def lisp(lambda_text, as_written=False, recognise=None):
     """An arbitrary model from the TEXT of the reference-style closure, e.g.
     lisp('(lambda (x &key m b &allow-other-keys) (+ b (* m x)))').  The body is translated to a
-    C expression (sexpr.py) and compiled for gfx950 at walker-create time (hiprtc).
+    C expression (sexpr.py) and handed to libmhx (mhx_set_function_expr), which compiles it for
+    gfx950 at walker-create time (hiprtc) - or, when the body IS a polynomial background plus
+    Gaussian / Lorentzian peaks a*exp(-((x-mu)/w)^2) (a/(1+((x-mu)/w)^2)), serves it with that
+    enumerated model's kernels (recognised below the C ABI, csrc/mhx_expr.cpp: the Lisp shim's
+    expr-model gets the same).
 
-    recognise: a body that IS a polynomial background plus Gaussian (or Lorentzian) peaks of the
-    form a*exp(-((x-mu)/w)^2) (a/(1+((x-mu)/w)^2)) is handed to the engine as that enumerated
-    model instead - same function, evaluated with the peak kernels' fused arithmetic (a few ulp
-    from the closure's own rounding, well inside the parity tolerance) and their tile-level
-    skipping.  recognise=False always compiles the expression as written."""
+    as_written=True: the walker's engine compiles every expression exactly as written
+    (mhx_set_expr_recognition).  `recognise` is accepted and ignored: until round 4 this module
+    did the recognising itself."""
+    del recognise
     from . import sexpr
-    if recognise:
-        hit = sexpr.recognise_peaks(lambda_text)
-        if hit is not None:
-            model_id, shape, keys = hit
-            m = Model(model_id, keys, shape)
-            # (an expression likelihood needs an expression model: walker_create falls back)
-            m.source_expr = sexpr.lambda_to_expr(lambda_text)
-            return m
     keys, expr = sexpr.lambda_to_expr(lambda_text)
-    return Model(capi.MODEL_EXPR, keys, expr=expr)
+    m = Model(capi.MODEL_EXPR, keys, expr=expr)
+    m.as_written = bool(as_written)
+    return m
+
+
+def classify(lambda_text):
+    """What libmhx makes of a closure's text (mhx_expr_classify; needs no GPU): (model id, shape,
+    keys in that model's local order) - (MODEL_EXPR, (), the closure's keys) when it is compiled
+    as written."""
+    import ctypes as C
+    from . import sexpr
+    keys, cexpr = sexpr.lambda_to_expr(lambda_text)
+    names = (C.c_char_p * max(len(keys), 1))(*[k.encode() for k in keys])
+    model, n = C.c_int32(0), C.c_int32(0)
+    shape = (C.c_int32 * 2)()
+    order = (C.c_int32 * max(len(keys), 1))()
+    capi.check(capi.lib().mhx_expr_classify(cexpr.encode(), names, len(keys), C.byref(model), shape,
+                                            order, C.byref(n)))
+    if model.value == capi.MODEL_EXPR:
+        return capi.MODEL_EXPR, (), keys
+    sh = () if model.value == capi.MODEL_POLY else (shape[0], shape[1])
+    return model.value, sh, [keys[order[j]] for j in range(n.value)]
 
 
 def expr(c_expression, keys):

@@ -241,13 +241,9 @@ def walker_create(function=None, data=None, params=None, data_error=None, log_li
     eng = Engine(n_chains, len(keys), K, device=device, seed=seed, chain_offset=chain_offset,
                  adapt_mode=adapt_mode, history_capacity=history_capacity,
                  poisson_logfact_double=poisson_logfact_double)
+    if any(getattr(f, "as_written", False) for f in fns):
+        eng.set_expr_recognition(False)
     for k, f in enumerate(fns):
-        if isinstance(liks[k], LikelihoodExpr) and getattr(f, "source_expr", None):
-            # a closure that was recognised as an enumerated peaks model (models.lisp) goes back to
-            # being an expression: expression likelihoods are compiled next to expression models
-            from .models import Model as _Model
-            ekeys, eexpr = f.source_expr
-            fns[k] = f = _Model(capi.MODEL_EXPR, ekeys, expr=eexpr)
         missing = [q for q in f.keys if q not in keys]
         if missing:
             raise KeyError("function %d reads keys %s that :params does not supply" % (k, missing))

@@ -11,7 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
-_LIB_PATH = os.path.join(ORACLE_DIR, "libmhx_oracle.so")
+# MHX_ORACLE_LIBRARY: another build of the same sources (oracle/Makefile: asan)
+_LIB_PATH = os.environ.get("MHX_ORACLE_LIBRARY") or os.path.join(ORACLE_DIR, "libmhx_oracle.so")
 
 f64p = C.POINTER(C.c_double)
 i32p = C.POINTER(C.c_int32)

@@ -31,7 +31,7 @@ def test_bench_line_at_the_drivers_arguments():
     assert d["config"]["chains_per_gpu"] == 4096 and d["config"]["n_points"] == 100000
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 / 4096 - 1.0) < 1e-9
     r = d["roofline"]
-    assert r["bound"] == "fp64_valu" and 0.3 < r["frac"] <= 1.0 and r["instr_source_stale"] is False
+    assert r["bound"] == "fp64_valu_issue" and r["unit"] == "G wave-instr/s" and 0.3 < r["frac"] <= 1.0 and r["instr_source_stale"] is False
     assert r["kernel_ms_per_launch"] * 1e-3 <= d["ms_per_step"] * 1e-3 * 20 * 1.001
     assert d["build"]["id"].startswith("csrc:")
     assert d["value_direct_form"] > 0 and d["direct_form"]["ratio_to_value"] > 1.0

@@ -257,22 +257,44 @@ def test_custom_likelihood_errors(mhx):
 
 
 def test_recognised_peak_closure_runs_on_the_peak_kernels(mhx, orc):
-    """models.lisp() recognises background + Gaussian peaks and hands the enumerated model over:
-    same kernel, same bits as models.gauss_peaks(); the closure compiled as written agrees within
-    the stated tolerance"""
+    """the recognition lives BELOW the C ABI (mhx_set_function_expr,
+    csrc/mhx_expr.cpp).  models.lisp() only translates the closure's text - exactly what the Lisp
+    shim's expr-model does - and libmhx serves background + Gaussian peaks with the enumerated
+    model's kernel: same kernel name, same bits as models.gauss_peaks() over a 1200-step walk.
+    as_written=True (mhx_set_expr_recognition) compiles the text and agrees within the stated
+    tolerance; a body that is not of the shape is compiled as written whatever the switch says."""
     s = pb.two_peak(n=5000, seed=91)
     x, y, sig, _ = s.data[0]
     params = [":b0", 0.5, ":b1", 0.3, ":a1", 1.0, ":mu1", 0.3, ":w1", 0.05, ":a2", 0.7, ":mu2", 0.7, ":w2", 0.08]
+    cross = TWO_PEAK.replace("(* a1 (exp", "(* a1 (+ 1 (* 0 b1)) (exp")           # a cross term
+    cube = TWO_PEAK.replace("(expt (/ (- x mu2) w2) 2)", "(expt (/ (- x mu2) w2) 3)")
     ws = [mhx.walker_create(function=f, data=[x, y], params=params, data_error=sig, n_chains=3, seed=5)
-          for f in (mhx.models.lisp(TWO_PEAK),
+          for f in (mhx.models.lisp(TWO_PEAK, recognise=False),     # (the keyword of rounds 2-3: ignored)
                     mhx.models.gauss_peaks(["b0", "b1"], [("a1", "mu1", "w1"), ("a2", "mu2", "w2")]),
-                    mhx.models.lisp(TWO_PEAK, recognise=False))]
+                    mhx.models.lisp(TWO_PEAK, as_written=True),
+                    mhx.models.lisp(cross), mhx.models.lisp(cube))]
     names = [w.engine.kernel_name() for w in ws]
-    assert names[0] == names[1] and "gauss22_normal" in names[0] and "rtc[expr" in names[2]
+    assert names[0] == names[1] and "gauss22_normal" in names[0], names
+    assert all("rtc[expr" in n for n in names[2:]), names
     p = [w.last_step().prob for w in ws]
     assert p[0] == p[1]
     op = s.oracle(orc)
     assert abs(p[2] - p[0]) <= 2 * REL * op.abs_terms(s.theta_star)
+    assert abs(p[3] - p[0]) <= 2 * REL * op.abs_terms(s.theta_star)
+    assert p[4] != p[0]
     for w in ws[:2]:
         mhx.walker_adaptive_steps(w, 1200)
-    assert np.array_equal(ws[0].engine.state()["theta"], ws[1].engine.state()["theta"])
+    a, b = ws[0].engine.state(), ws[1].engine.state()
+    for k in ("theta", "logpost", "best_theta", "age", "length"):
+        assert np.array_equal(a[k], b[k]), k
+    # an expression likelihood keeps its function an expression (it reads `model` from one)
+    w = mhx.walker_create(function=mhx.models.lisp(TWO_PEAK), data=[x, y], params=params, data_error=sig,
+                          log_liklihood=mhx.create_log_liklihood_function(
+                              "(lambda (y model error) (* -1/2 (expt (/ (- y model) error) 2)))"),
+                          n_chains=2, seed=5)
+    assert "rtc[expr:expr" in w.engine.kernel_name(), w.engine.kernel_name()
+    # a permuted key order in the plist: the gather map is permuted into the model's order
+    perm = [":w2", 0.08, ":mu2", 0.7, ":a2", 0.7, ":b1", 0.3, ":w1", 0.05, ":mu1", 0.3, ":a1", 1.0, ":b0", 0.5]
+    wp = mhx.walker_create(function=mhx.models.lisp(TWO_PEAK), data=[x, y], params=perm, data_error=sig,
+                           n_chains=3, seed=5)
+    assert "gauss22_normal" in wp.engine.kernel_name() and wp.last_step().prob == p[0]

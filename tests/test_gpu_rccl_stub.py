@@ -3,7 +3,13 @@ ncclAllReduce per engine inside ncclGroupStart/End on the engines' own streams) 
 test box has.  The real librccl wants a device per rank, so these tests run libmhx against the
 stand-in of tests/stub_rccl (same eight entry points and calling conventions, host-staged sum in
 rank order; MHX_RCCL_LIBRARY selects it, MHX_GROUP_FORCE_RCCL=1 lets engines that share a device
-take the branch).  libmhx opens its RCCL once per process, so every case is a child process.
+take the branch).  That switch exists only in tests/hooks/libmhx_hooks.so - the same objects as
+libmhx.so with -DMHX_DEBUG_HOOKS, chosen through MHX_LIBRARY; the release library has no test
+switches.  libmhx opens its RCCL once per process, so every case is a child process.
+
+And the REAL librccl through the same branch: a forced group of ONE device (which the real
+library accepts) runs ncclCommInitAll / ncclGroupStart / ncclAllReduce / ncclGroupEnd - the three
+prototypes libmhx restates by hand - on the one GPU of the box.
 
 Also here: the process-exit regression of round 2 (a full-suite process that had used RCCL and
 hiprtc aborted with `double free or corruption` after its work was done, while librccl was opened
@@ -20,6 +26,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 STUB = os.path.join(HERE, "stub_rccl", "librccl_stub.so")
+HOOKS = os.path.join(HERE, "hooks", "libmhx_hooks.so")
 
 PRELUDE = """
 import os, sys
@@ -48,7 +55,9 @@ def run_child(body, tmp_path, stub=True, force=True, fail=None, extra_env=None):
         env["MHX_RCCL_LIBRARY"] = STUB
         env["MHX_STUB_RCCL_LOG"] = str(log)
     if force:
+        assert os.path.exists(HOOKS), "tests/hooks/libmhx_hooks.so is not built (__graft_entry__.build())"
         env["MHX_GROUP_FORCE_RCCL"] = "1"
+        env["MHX_LIBRARY"] = HOOKS
     if fail:
         env["MHX_STUB_RCCL_FAIL"] = fail
     env.update(extra_env or {})
@@ -242,7 +251,8 @@ def test_process_with_rccl_and_hiprtc_exits_cleanly(tmp_path):
             "(lambda (x &key b0 b1 a1 mu1 w1 a2 mu2 w2 &allow-other-keys)"
             " (+ (+ b0 (* b1 x)) (* a1 (exp (- (expt (/ (- x mu1) w1) 2))))"
             "    (* a2 (exp (- (expt (/ (- x mu2) w2) 2))))))")
-        ex.set_function_expr(0, cexpr, keys, list(range(8)))   # hiprtc
+        ex.set_expr_recognition(False)                          # as written: hiprtc
+        ex.set_function_expr(0, cexpr, keys, list(range(8)))
         ex.init_chains(th0[:8])
         assert "rtc" in ex.kernel_name()
         assert torch.cuda.is_available()
@@ -254,13 +264,42 @@ def test_process_with_rccl_and_hiprtc_exits_cleanly(tmp_path):
     assert out.returncode == 0, (out.returncode, out.stderr[-3000:])
 
 
+def test_one_device_group_through_the_real_rccl(tmp_path):
+    """the first N > 1 run is the driver's, and a wrong hand-restated prototype
+    of ncclCommInitAll / ncclGroupStart / ncclGroupEnd (csrc/mhx_engine.cpp) would show only
+    there.  A forced group of ONE device takes the communicator branch against the REAL librccl:
+    ncclCommInitAll(comms, 1, {0}), and per pooled tick ncclGroupStart, one ncclAllReduce of 73
+    doubles on the engine's stream, ncclGroupEnd.  450 iterations (two ticks) = the plain pooled
+    engine bit for bit; exit status 0 with everything left to the interpreter's exit."""
+    out, _ = run_child("""
+        s = pb.two_peak(n=2000, seed=5)
+        C_ = 64
+        th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=7)
+        mode = mhx.capi.ADAPT_POOLED
+        assert mhx.capi.lib().mhx_build_id().decode().endswith("+hooks")
+        g = mhx.Group(C_, s.d, s.K, devices=[0], seed=11, adapt_mode=mode)
+        s.apply(g)
+        plain = s.engine(mhx, C_, seed=11, adapt_mode=mode)
+        a, b = walk(plain, th0, 450), walk(g, th0, 450)
+        for k in ("theta", "logpost", "best_theta", "age", "length"):
+            assert np.array_equal(a[k], b[k]), k
+        pa, pg = plain.pooled(), g.engines[0].pooled()
+        assert pg["refreshes"] == 2 and pa["refreshes"] == 2
+        assert np.array_equal(pa["stats"], pg["stats"]) and np.array_equal(pa["L"], pg["L"])
+        assert pg["valid"]
+        print("ok", flush=True)
+    """, tmp_path, stub=False, force=True)
+    assert "ok" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+    assert out.returncode == 0, (out.returncode, out.stderr[-3000:])
+
+
 def test_bench_gpus_2_in_one_process_rehearsed_on_one_gpu(tmp_path):
     """`python3 bench.py --gpus 2` without a launcher: ONE process, mhx.Group over two engines,
     pooled adaptation with the tick's collective inside the timed region - rehearsed here with
     both engines on device 0 and the stand-in librccl.  One JSON line, whole-job rate, the
     contract's fields."""
     import json
-    env = dict(os.environ, MHX_RCCL_LIBRARY=STUB, MHX_GROUP_FORCE_RCCL="1",
+    env = dict(os.environ, MHX_RCCL_LIBRARY=STUB, MHX_GROUP_FORCE_RCCL="1", MHX_LIBRARY=HOOKS,
                MHX_STUB_RCCL_LOG=str(tmp_path / "calls.log"))
     env.pop("RANK", None)
     env.pop("WORLD_SIZE", None)

@@ -418,3 +418,71 @@ def test_split_with_expression_likelihood(mhx):
         assert st["best_logpost"][0] > w.engine.logpost(start[None, :])[0]
     # (the stored log-posterior of a chain that moved is the split sweep's value at an accepted
     # proposal, so the comparison with mhx_logpost above is a comparison of the two sweeps)
+
+
+def test_tile_sliced_repacking_does_not_depend_on_how_the_host_chunks_its_calls(mhx):
+    """the tile-sliced mode regroups the partial sums when it repacks, so WHEN it
+    repacks must be a function of the walk, not of the host's call sequence.  Repacking is
+    considered only where the iterations since begin are a multiple of the portion length
+    (launch_steps_enqueue cuts its launches there whatever the caller asked for): complete runs
+    driven in chunks of 600, of 137 with a count after each, and in one call end in the same
+    bits."""
+    s = pb.two_peak(n=30000, seed=31)
+    chains, n = 72, 7000
+    th0 = pb.perturbed(s.theta_star, chains, 0.01, seed=8)
+    res = []
+    for chunk, count in ((600, True), (137, True), (1 << 40, False), (512, False)):
+        e, name = ts_engine(mhx, s, chains, None, seed=17)
+        assert "tsplit x" in name, name
+        e.init_chains(th0)
+        e.adaptive_begin(n, 10.0, 1)
+        for _ in range(200):
+            left = e.adaptive_advance(chunk, count=count)
+            if (count and left == 0) or (not count and (e.chain_status()[0] != mhx.capi.CHAIN_RUNNING).all()):
+                break
+        st, stat = e.state(), e.chain_status()[0]
+        assert (stat == mhx.capi.CHAIN_DONE).all()
+        res.append(st)
+        e.close()
+    assert len(set(res[0]["age"].tolist())) > 3          # they did end at different times: repacked
+    for other in res[1:]:
+        for k in ("theta", "logpost", "best_theta", "best_logpost", "age", "length"):
+            assert np.array_equal(res[0][k], other[k]), k
+
+
+def test_slot_map_grows_when_the_problem_changes_the_mode(mhx):
+    """a tile-sliced engine runs to completion (compact_tsplit allocates the
+    slot map for its own needs), the caller swaps in a SHORT dataset - finalize picks the batch
+    kernels, whose initial deal writes a map of cus * W entries - and runs again.  The map is
+    sized per deal now (put_slot_map) and the identity map restored when a problem is finalised;
+    before, the second run wrote 2048 ints into a 1032-int allocation."""
+    long_, short = pb.two_peak(n=30000, seed=3), pb.two_peak(n=900, seed=3)
+    for chains in (64, 1024):
+        th0 = pb.perturbed(long_.theta_star, chains, 0.01, seed=2)
+        e, name = ts_engine(mhx, long_, chains, None, seed=21)
+        assert "tsplit x" in name, name
+        e.init_chains(th0)
+        e.adaptive_begin(3000, 10.0, 1)
+        while e.adaptive_advance(512):
+            pass
+        x, y, sg, lik = short.data[0]
+        e.set_dataset(0, x, y, sg, lik)
+        # a run that was begun on the old problem is over
+        with pytest.raises(mhx.MhxError):
+            e.adaptive_advance(10)
+        name2 = e.kernel_name()
+        assert "split" not in name2, name2
+        e.init_chains(th0)
+        e.adaptive_begin(2500, 10.0, 1)
+        while e.adaptive_advance(700):
+            pass
+        st = e.state()
+        ref = short.engine(mhx, chains, seed=21)
+        ref.init_chains(th0)
+        ref.adaptive_begin(2500, 10.0, 1)
+        ref.adaptive_advance(1 << 40)
+        rs = ref.state()
+        for k in ("theta", "logpost", "age"):
+            assert np.array_equal(st[k], rs[k]), (chains, k)
+        e.close()
+        ref.close()

@@ -137,32 +137,78 @@ def test_rejects_unsupported_forms(sx):
     assert sx.mangle(":much-better-param-name1") == "much_better_param_name1"
 
 
-def test_peak_closures_are_recognised(sx):
-    """models.lisp() hands closures that ARE background + Gaussian / Lorentzian peaks to the
-    engine as the enumerated model (sexpr.recognise_peaks)"""
-    R = sx.recognise_peaks
-    assert R("(lambda (x &key b0 b1 a1 mu1 w1 a2 mu2 w2 &allow-other-keys) (+ (+ b0 (* b1 x))"
-             " (* a1 (exp (- (expt (/ (- x mu1) w1) 2)))) (* a2 (exp (- (expt (/ (- x mu2) w2) 2))))))") == \
-        (1, (2, 2), ["b0", "b1", "a1", "mu1", "w1", "a2", "mu2", "w2"])
-    assert R("(lambda (x &key bg a mu w &allow-other-keys) (+ bg (* (exp (* -1 (expt (/ (- x mu) w) 2d0))) a)))") == \
-        (1, (1, 1), ["bg", "a", "mu", "w"])
-    assert R("(lambda (x &key a x0 g c m q &allow-other-keys) (+ (* q (expt x 2)) c (* m x)"
-             " (* a (/ 1 (1+ (* (/ (- x x0) g) (/ (- x x0) g)))))))") == (2, (3, 1), ["c", "m", "q", "a", "x0", "g"])
-    assert R("(lambda (x &key a x0 g &allow-other-keys) (/ a (+ (expt (/ (- x x0) g) 2) 1)))") == \
-        (2, (0, 1), ["a", "x0", "g"])
-    for text in (
-            "(lambda (x &key a mu w &allow-other-keys) (* 2 a (exp (- (expt (/ (- x mu) w) 2)))))",   # extra factor
-            "(lambda (x &key a mu &allow-other-keys) (* a (exp (- (expt (/ (- x mu) a) 2)))))",       # a key used twice
-            "(lambda (x &key a mu w &allow-other-keys) (* a (exp (- (expt (/ (- x mu) w) 4)))))",     # not a Gaussian
-            "(lambda (x &key a mu w c &allow-other-keys) (+ (* c (expt x 2)) (* a (exp (- (expt (/ (- x mu) w) 2))))))",  # gap in bg
-            "(lambda (x &key a mu w (c 1d0) &allow-other-keys) (+ c (* a (exp (- (expt (/ (- x mu) w) 2))))))",           # defaults
-            "(lambda (x &key a mu w b g &allow-other-keys) (+ (* a (exp (- (expt (/ (- x mu) w) 2)))) (/ b (+ 1 (expt (/ (- x mu) g) 2)))))"):
-        assert R(text) is None, text
-    assert R("(lambda (x &key m b &allow-other-keys) (+ b (* m x)))") == (0, (), ["b", "m"])
-    assert R("(lambda (x &key b m c d &allow-other-keys) (+ b (* m x) (* c x x) (* d x x x)))") == (0, (), ["b", "m", "c", "d"])
-    assert R("(lambda (x &key m b &allow-other-keys) (+ b (* -3 m) (* m x)))") is None
+CORPUS_HIT = [
+    ("(lambda (x &key b0 b1 a1 mu1 w1 a2 mu2 w2 &allow-other-keys) (+ (+ b0 (* b1 x))"
+     " (* a1 (exp (- (expt (/ (- x mu1) w1) 2)))) (* a2 (exp (- (expt (/ (- x mu2) w2) 2))))))",
+     (1, (2, 2), ["b0", "b1", "a1", "mu1", "w1", "a2", "mu2", "w2"])),
+    ("(lambda (x &key bg a mu w &allow-other-keys) (+ bg (* (exp (* -1 (expt (/ (- x mu) w) 2d0))) a)))",
+     (1, (1, 1), ["bg", "a", "mu", "w"])),
+    ("(lambda (x &key a x0 g c m q &allow-other-keys) (+ (* q (expt x 2)) c (* m x)"
+     " (* a (/ 1 (1+ (* (/ (- x x0) g) (/ (- x x0) g)))))))", (2, (3, 1), ["c", "m", "q", "a", "x0", "g"])),
+    ("(lambda (x &key a x0 g &allow-other-keys) (/ a (+ (expt (/ (- x x0) g) 2) 1)))",
+     (2, (0, 1), ["a", "x0", "g"])),
+    ("(lambda (x &key m b &allow-other-keys) (+ b (* m x)))", (0, (), ["b", "m"])),
+    ("(lambda (x &key b m c d &allow-other-keys) (+ b (* m x) (* c x x) (* d x x x)))",
+     (0, (), ["b", "m", "c", "d"])),
+    # a key the closure declares and never reads is not part of the model
+    ("(lambda (x &key a mu w spare &allow-other-keys) (* a (exp (- (expt (/ (- x mu) w) 2)))))",
+     (1, (0, 1), ["a", "mu", "w"])),
+    # config 3's shape: constant background + five peaks
+    ("(lambda (x &key bg a1 m1 w1 a2 m2 w2 a3 m3 w3 a4 m4 w4 a5 m5 w5 &allow-other-keys) (+ bg"
+     + "".join(" (* a%d (exp (- (expt (/ (- x m%d) w%d) 2))))" % (i, i, i) for i in range(1, 6)) + "))",
+     (1, (1, 5), ["bg"] + [k % i for i in range(1, 6) for k in ("a%d", "m%d", "w%d")])),
+]
+CORPUS_MISS = [
+    "(lambda (x &key a mu w &allow-other-keys) (* 2 a (exp (- (expt (/ (- x mu) w) 2)))))",   # extra factor
+    "(lambda (x &key a mu &allow-other-keys) (* a (exp (- (expt (/ (- x mu) a) 2)))))",       # a key used twice
+    "(lambda (x &key a mu w &allow-other-keys) (* a (exp (- (expt (/ (- x mu) w) 4)))))",     # not a Gaussian
+    "(lambda (x &key a mu w &allow-other-keys) (* a (exp (- (expt (/ (- x mu) w) 3)))))",     # a cube
+    "(lambda (x &key a mu w c &allow-other-keys) (+ (* c (expt x 2)) (* a (exp (- (expt (/ (- x mu) w) 2))))))",  # gap in bg
+    "(lambda (x &key a mu w b g &allow-other-keys) (+ (* a (exp (- (expt (/ (- x mu) w) 2)))) (/ b (+ 1 (expt (/ (- x mu) g) 2)))))",
+    "(lambda (x &key m b &allow-other-keys) (+ b (* -3 m) (* m x)))",
+    "(lambda (x &key a b mu w &allow-other-keys) (* a b (exp (- (expt (/ (- x mu) w) 2)))))",  # cross term
+    "(lambda (x &key a mu w &allow-other-keys) (- (* a (exp (- (expt (/ (- x mu) w) 2))))))",  # negated peak
+    "(lambda (x &key a mu w &allow-other-keys) (if (> x mu) a w))",
+    "(lambda (x &key a mu w &allow-other-keys) (* a (exp (- (expt (/ (- mu x) w) 2)))))",      # mu - x
+]
+
+
+def test_peak_closures_are_recognised_below_the_abi(sx):
+    """libmhx (csrc/mhx_expr.cpp, reached through mhx_expr_classify - host logic, no GPU) hands
+    closures that ARE background + Gaussian / Lorentzian peaks to the enumerated models; the
+    independent statement of the rule on the Lisp form (tests/sexpr_recognise.py) agrees closure by
+    closure, hits and misses."""
     import lisp_mcmc_amd
-    m = lisp_mcmc_amd.models.lisp("(lambda (x &key bg a mu w &allow-other-keys) (+ bg (* a (exp (- (expt (/ (- x mu) w) 2))))))")
-    assert (m.model_id, m.shape, m.keys) == (1, (1, 1), ["bg", "a", "mu", "w"]) and m.source_expr[0] == ["bg", "a", "mu", "w"]
-    m = lisp_mcmc_amd.models.lisp("(lambda (x &key bg a mu w &allow-other-keys) (+ bg (* a (exp (- (expt (/ (- x mu) w) 2))))))", recognise=False)
-    assert m.model_id == lisp_mcmc_amd.capi.MODEL_EXPR
+    import sexpr_recognise
+    R = sexpr_recognise.recognise_peaks
+    M = lisp_mcmc_amd.models
+    for text, want in CORPUS_HIT:
+        assert M.classify(text) == want, text
+        if "spare" not in text:                     # (the helper wants every key used)
+            assert R(text) == want, text
+    for text in CORPUS_MISS:
+        got = M.classify(text)
+        assert got[0] == lisp_mcmc_amd.capi.MODEL_EXPR and got[1] == (), text
+        assert R(text) is None, text
+    # C-syntax spellings a plain-C host may use
+    import ctypes as C
+    lib = lisp_mcmc_amd.capi.lib()
+
+    def classify_c(cexpr, names):
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        model, n = C.c_int32(0), C.c_int32(0)
+        shape, order = (C.c_int32 * 2)(), (C.c_int32 * len(names))()
+        assert lib.mhx_expr_classify(cexpr.encode(), arr, len(names), C.byref(model), shape, order,
+                                     C.byref(n)) == 0, lib.mhx_last_error()
+        return model.value, (shape[0], shape[1]), [names[order[j]] for j in range(n.value)]
+    assert classify_c("c + A*exp(-pow((x - m)/s, 2.0))", ["A", "m", "s", "c"]) == (1, (1, 1), ["c", "A", "m", "s"])
+    assert classify_c("A*exp(-((x-m)/s)*((x-m)/s)) + c + d*x", ["A", "m", "s", "c", "d"]) == \
+        (1, (2, 1), ["c", "d", "A", "m", "s"])
+    assert classify_c("A*(1/(1 + ipow((x - m)/s, 2)))", ["A", "m", "s"]) == (2, (0, 1), ["A", "m", "s"])
+    assert classify_c("A*exp(-((x-m)/s)*((x-m)/t))", ["A", "m", "s", "t"])[0] == 7
+    assert classify_c("x > m ? A : s", ["A", "m", "s"])[0] == 7
+    assert lib.mhx_expr_classify(b"A*foo(x)", (C.c_char_p * 1)(b"A"), 1, C.byref(C.c_int32()), None, None,
+                                 None) == lisp_mcmc_amd.capi.EINVAL
+    m = M.lisp("(lambda (x &key bg a mu w &allow-other-keys) (+ bg (* a (exp (- (expt (/ (- x mu) w) 2))))))")
+    assert m.model_id == lisp_mcmc_amd.capi.MODEL_EXPR and not m.as_written   # libmhx decides
+    assert M.lisp("(lambda (x &key m b &allow-other-keys) (+ b (* m x)))", as_written=True).as_written
