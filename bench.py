@@ -6,7 +6,7 @@ chain of the batch: propose, evaluate the full log-posterior over all data point
 reject, history push, controller bookkeeping (incl. the 200-step proposal adaptation when it
 falls inside the timed region).  Inputs are resident in HBM before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|poly7|c1|c2expr|g23]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|poly7|c1|c2expr|c2written|g23]
 
 N > 1 runs either way, chains sharded by contiguous global id ranges (weak scaling: --chains per
 GPU), datasets replicated, no data-path collective in the reference's per-walker adaptation mode;
@@ -305,7 +305,10 @@ def main():
         if have <= max(devices):
             raise SystemExit("device %d asked for but this process sees %d GPU(s)" % (max(devices), have))
 
-    as_expr = args.workload == "c2expr"  # config 2 with the model given as a Lisp closure text
+    # config 2 with the model given as the TEXT of its Lisp closure: c2expr - what a Lisp host hands
+    # over; libmhx recognises the peaks (csrc/mhx_expr.cpp) and runs config 2's kernel; c2written -
+    # the same text compiled exactly as written (mhx_set_expr_recognition(0): rounds 1-3's c2expr)
+    as_expr = args.workload in ("c2expr", "c2written")
     spec, chains, b_pt, desc = synth_workload("c2" if as_expr else args.workload)
     if args.chains:
         chains = args.chains
@@ -322,12 +325,16 @@ def main():
                 " (+ (+ b0 (* b1 x)) (* a1 (exp (- (expt (/ (- x mu1) w1) 2))))"
                 "    (* a2 (exp (- (expt (/ (- x mu2) w2) 2))))))")
             for e in f.engines:
+                if args.workload == "c2written":
+                    e.set_expr_recognition(False)
                 e.set_function_expr(0, cexpr, keys, list(range(8)))
         return f
 
     fleet = make()
     if as_expr:
-        desc += " [model compiled at run time from its Lisp closure text]"
+        desc += (" [model given as its Lisp closure text, compiled at run time exactly as written]"
+                 if args.workload == "c2written" else
+                 " [model given as its Lisp closure text: recognised below the C ABI, config 2's kernel]")
     collective = None
     if pooled and n_gpus > 1 and not per_rank:
         collective = "ncclCommInitAll + ncclAllReduce in ncclGroupStart/End (one host process, mhx_group_*)"
@@ -600,6 +607,43 @@ def main():
             out["direct_form"]["frac"] = (ippd * chains * args.steps * n_points / 64.0 * 128.0
                                           / (dk["total_ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS)
         direct.close()
+    # ... and the same walk on an x that is a grid only PIECEWISE (tests/problems.py, piecewise_x:
+    # three scans of different steps laid end to end, one jittered window, the first step again -
+    # what an instrument file often looks like): since round 4 every 2048-point window on a grid
+    # takes the recurrence with its own step and only the junction / jittered windows the direct
+    # form; until then the whole dataset took the direct form (value_direct_form).
+    if (rank == 0 and not per_rank and n_gpus == 1 and not args.no_direct and args.workload == "c2"):
+        import copy
+        import problems as pb
+        pspec = copy.copy(spec)
+        x0, y0, sg0, lk0 = spec.data[0]
+        xp = pb.piecewise_x(len(x0), seed=11)
+        rngp = np.random.Generator(np.random.Philox(key=0x5EED0004))
+        yp = pb.model_eval_np(pb.GAUSS, (2, 2), spec.theta_star, xp) + sg0 * rngp.standard_normal(len(x0))
+        pspec.data = [(xp, yp, sg0, lk0)]
+        pw = Fleet(mhx, pspec, chains, devices, pooled, seed=0x5EED0003, chain_offset=first_id)
+        pw.start(th0, n_adapt, l0)
+        for _ in range(w_n):
+            pw.advance(w_per)
+        n_disp += pw.timing(reset=True)[0]["launches"]
+        p0 = pw.steps()
+        sync()
+        tp0 = time.perf_counter()
+        for _ in range(n_launch):
+            pw.advance(per_launch)
+        sync()
+        tpw = time.perf_counter() - tp0
+        pk = pw.timing()[0]
+        out["value_piecewise"] = (pw.steps() - p0) / tpw
+        out["piecewise"] = {
+            "what": "the same walk on an x that is three scans of different steps laid end to end, one "
+                    "jittered window, the first step again: the recurrence window by window (FnDesc::tgh), "
+                    "the direct form only in the junction and jittered windows",
+            "kernel_ms_per_launch": pk["avg_ms"],
+            "dispatches": [n_disp, n_disp + pk["launches"]],
+            "ratio_to_value": out["value"] / out["value_piecewise"]}
+        n_disp += pk["launches"]
+        pw.close()
     if rank == 0 and not per_rank and n_gpus == 1 and not args.no_cpu:
         ncpu, cinfo = effective_cores()
         one = cpu_baseline(spec, th0, args.cpu_seconds * 0.4, n_adapt, 1, l0)

@@ -908,6 +908,34 @@ struct PeaksModel {
     // broadcasts the window's word with readlane, so the tests in eval() are scalar branches
     return m | (guard ? kGuardBit : 0u);
   }
+  // What a sweep over fn will cost this chain, in quarter VALU instructions per point of a lane
+  // and window, summed over the windows (wave-uniform; only differences between chains matter).
+  // Used to DEAL the proposals of a workgroup to its wave slots (group_logpost): the chains of a
+  // workgroup meet at a barrier every window and the four waves of a SIMD share its issue slots,
+  // so a SIMD that drew four expensive proposals holds everybody up.  Per window and peak, by the
+  // kernel's own rules: left out 0, recurrence 3 (4.75 / 6.5 when re-seeded inside the window),
+  // direct table exp 14, a guarded window 18 for every peak.
+  static __device__ __forceinline__ int sweep_cost(const Prep& p, const FnDesc& fn) {
+    static_assert(kHasSkip, "per-window masks");
+    const int l = lane_id();
+    const int64_t nw = (fn.n + kPadPoints - 1) / kPadPoints;
+    int cost = 0;
+    for (int64_t w0 = 0; w0 < nw; w0 += kWave) {
+      const int64_t wi = w0 + l;
+      const int64_t ti = wi < nw ? wi : nw - 1;
+      const unsigned tw = tile_mask(p, fn.txlo[ti], fn.txhi[ti]);
+      int cw = 0;
+#pragma unroll
+      for (int k = 0; k < NPK; ++k) {
+        const unsigned b = 1u << k;
+        const int ck = (p.rmask & b) ? ((p.s8 & b) ? 26 : ((p.s16 & b) ? 19 : 12)) : 56;
+        cw += (tw & b) ? ck : 0;
+      }
+      cw = (tw & kGuardBit) ? 72 * NPK : cw;
+      cost += wi < nw ? cw + (p.bgrec ? 0 : 4) : 0;
+    }
+    return __builtin_amdgcn_readfirstlane(wave_sum_i(cost));
+  }
   // scratch: kScratchDoubles doubles of the wave's own LDS (kSeedInLds; ignored otherwise)
   template <class PF>
   static __device__ __forceinline__ Prep prepare(PF pf, const FnDesc& fn, double* scratch = nullptr) {
@@ -997,6 +1025,53 @@ struct PeaksModel {
     p.bgH = NBG == 2 ? uniform_f64(p.bg[1] * fn.grid_H) : 0.0;
     if constexpr (kSeedInLds) __builtin_amdgcn_wave_barrier();  // (the wave's own LDS writes above)
     return p;
+  }
+  // PER-WINDOW GRIDS.  The recurrence needs the step of t from one point of a lane to its next,
+  // D = 64 h iw - a property of the 2048-point window being swept, not of the dataset: real
+  // spectra are often piecewise uniform (concatenated scans, a re-gridded stretch), and a seed is
+  // formed at the lane's ACTUAL x anyway.  For datasets that are not one grid the host gives every
+  // window its own H = 64 h (0: not a grid; FnDesc::tgh, mhx_engine.cpp), and sweep() calls this
+  // when the window about to be swept has another H than the last one: what prepare() derives
+  // from fn.grid_H, restated for H (same operations: a dataset whose windows all carry one H
+  // gives the bits of the whole-dataset rule).  Rare by construction - runs of windows share
+  // their H bit for bit - so its cost (a degree-11 exp2 per peak) does not matter.
+  static __device__ __forceinline__ void regrid(Prep& p, double H) {
+    unsigned rmask = 0, s16 = 0, s8 = 0;
+#pragma unroll
+    for (int k = 0; k < NPK; ++k) {
+      const double iwk = uniform_f64(p.iw_of(k));
+      const double dl = H * iwk;  // D_k
+      const double rm2d_k = uniform_f64(-2.0 * dl), rnd2_k = uniform_f64(-(dl * dl));
+      if constexpr (kSeedInLds) {
+        if (lane_id() == 0) {
+          typedef __attribute__((address_space(3))) double* lds_wptr_t;
+          lds_wptr_t sc = (lds_wptr_t)p.sc;
+          sc[4 * k + 2] = rm2d_k;
+          sc[4 * k + 3] = rnd2_k;
+        }
+      } else {
+        p.rm2d[k] = rm2d_k;
+        p.rnd2[k] = rnd2_k;
+      }
+      p.rq[k] = uniform_f64(mexp2(2.0 * rnd2_k));
+      const bool base = kHasRec && kHasSkip && H != 0.0;
+      const double ad = fabs(dl);
+      const bool ok32 = base && (ad * (double)kSeedSteps <= 1.0);
+      const bool ok16 = kMultiSeed ? base && (ad * (double)(kSeedSteps / 2) <= 1.0) : ok32;
+      const bool ok8 = kMultiSeed ? base && (ad * (double)(kSeedSteps / 4) <= 1.0) : ok32;
+      rmask |= ok8 ? (1u << k) : 0u;
+      s16 |= (ok8 && !ok32) ? (1u << k) : 0u;
+      s8 |= (ok8 && !ok16) ? (1u << k) : 0u;
+    }
+    p.rmask = (unsigned)__builtin_amdgcn_readfirstlane((int)rmask);
+    p.s16 = (unsigned)__builtin_amdgcn_readfirstlane((int)s16);
+    p.s8 = (unsigned)__builtin_amdgcn_readfirstlane((int)s8);
+    p.bgrec = NBG >= 1 && NBG <= 2 && NPK <= 2 && p.rmask == (1u << NPK) - 1u;
+#ifdef MHX_NO_BGREC
+    p.bgrec = false;
+#endif
+    p.bgH = NBG == 2 ? uniform_f64(p.bg[1] * H) : 0.0;
+    if constexpr (kSeedInLds) __builtin_amdgcn_wave_barrier();
   }
   static __device__ __forceinline__ bool fast_ok(const Prep& p) { return p.fast; }
   // mask (wave-uniform, from tile_mask): bit k clear = peak k is a no-op for this tile

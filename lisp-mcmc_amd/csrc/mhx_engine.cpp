@@ -72,8 +72,10 @@ struct DevBuf {
 };
 
 struct Dataset {
-  DevBuf<double> x, y, w, c, txlo, txhi;
+  DevBuf<double> x, y, w, c, txlo, txhi, tgh;
   std::vector<double> hx;  // host copy of the padded x: tile ranges are formed per kernel family
+  size_t n = 0;            // data points (hx holds the pads too)
+  bool no_rec = false;     // MHX_NO_RECURRENCE=1 when the dataset was set
   bool set = false;
 };
 
@@ -242,6 +244,11 @@ struct mhx_engine {
   DevBuf<int32_t> split_pending;
   // tile-sliced split mode (k_split_tsweep): split_slices = slices of whole windows per function,
   // ts_table = their FnDescs [K][split_slices] on the device
+  // persistent split mode (k_persist): the per-chain split mode's slots, ONE launch for many
+  // iterations - when every workgroup of the launch is resident at once (finalize_problem)
+  bool persist = false;
+  DevBuf<unsigned long long> persist_msg;  // [C][64]: the chains' proposal blocks (mhx_types.hpp)
+  DevBuf<unsigned char> persist_part;      // [C][K][slots][16]: {partial sum, generation} pairs
   bool tsplit = false;
   int ts_initial = 0;  // slices a run starts with (compact_tsplit may cut finer as chains finish)
   // iterations the split modes have queued since the run began.  The tile-sliced mode repacks
@@ -433,6 +440,7 @@ int build_ts_table(mhx_engine* e, int ts) {
         if (f.c) g.c = f.c + off;
         if (f.txlo) g.txlo = f.txlo + off / kPadPoints;
         if (f.txhi) g.txhi = f.txhi + off / kPadPoints;
+        if (f.tgh) g.tgh = f.tgh + off / kPadPoints;
       }
       tab[(size_t)k * ts + sl] = g;
     }
@@ -501,6 +509,47 @@ int finalize_problem(mhx_engine* e) {
     f.txlo = D.txlo.p;
     f.txhi = D.txhi.p;
     f.n_tiles = (int64_t)nt;
+    // Per-window grids.  A dataset that is not ONE grid (grid_H == 0) may still be a grid window
+    // by window - concatenated scans, a re-gridded stretch, one jittered region: window w gets
+    // H_w = 64 h when its data points are x_first + i h to 8 ulp of the window's max |x| - first
+    // tried with the previous grid window's h, so that runs of windows on one grid carry the SAME
+    // bits (the kernel re-derives its constants only where H changes: PeaksModel::regrid), then
+    // with its own h = (x_last - x_first) / (points - 1) - and 0 otherwise (direct form there).
+    // MHX_NO_WINDOW_GRIDS=1: off (round 3's rule: one grid or none).
+    f.tgh = nullptr;
+    {
+      const char* nwg = getenv("MHX_NO_WINDOW_GRIDS");
+      if (f.grid_H == 0.0 && !D.no_rec && !(nwg && atoi(nwg) != 0) && D.n >= 2) {
+        std::vector<double> gh(ntp, 0.0);
+        double h_prev = 0.0;
+        bool any = false;
+        for (size_t t = 0; t < ntp; ++t) {
+          const size_t i0 = t * wp, cnt = std::min(wp, D.n > i0 ? D.n - i0 : 0);
+          if (cnt < 2) continue;
+          const double* xw = &D.hx[i0];
+          if (!std::isfinite(xw[0]) || !std::isfinite(xw[cnt - 1])) continue;
+          const double tol = 8.0 * 0x1p-52 * std::max(std::fabs(xw[0]), std::fabs(xw[cnt - 1]));
+          auto fits = [&](double h) {
+            if (h == 0.0 || !std::isfinite(h)) return false;
+            for (size_t i = 0; i < cnt; ++i)
+              if (!(std::fabs(xw[i] - (xw[0] + (double)i * h)) <= tol)) return false;
+            return true;
+          };
+          double h = h_prev;
+          if (!fits(h)) h = (xw[cnt - 1] - xw[0]) / (double)(cnt - 1);
+          if (!fits(h)) continue;
+          gh[t] = 64.0 * h;
+          h_prev = h;
+          any = true;
+        }
+        if (any) {
+          if (D.tgh.alloc(ntp, false) != hipSuccess)
+            return fail(MHX_ENOMEM, "hipMalloc of dataset %d's window grids failed", k);
+          HIP_TRY(hipMemcpy(D.tgh.p, gh.data(), ntp * sizeof(double), hipMemcpyHostToDevice));
+          f.tgh = D.tgh.p;
+        }
+      }
+    }
     // the one tile stays in LDS (sweep).  Measured (tools/ab_tree.sh, test.lisp's shape): +9 %
     // with one chain, -5 % with 512 and -15 % with 2048 chains: only the single-walker case, the
     // reference's own way of working, gets it
@@ -559,14 +608,30 @@ int finalize_problem(mhx_engine* e) {
   // skipping): 2.4-2.8x the run-time-dispatched generic kernels on configs 2 and 3.  The generic
   // kernels remain for MHX_FORCE_GENERIC=1 / MHX_NO_RTC_SPECIALISE=1 and for machines without
   // hiprtc.
+  {  // MHX_NO_DEAL=1: every wave judges its own chain's proposal (A/B runs; same bits either way)
+    const char* nd = getenv("MHX_NO_DEAL");
+    e->P.no_deal = (nd && atoi(nd) != 0) ? 1 : 0;
+  }
   const char* fg = getenv("MHX_FORCE_GENERIC");
   const char* ns = getenv("MHX_NO_RTC_SPECIALISE");
   const bool force_generic = fg && atoi(fg) != 0;
   const bool specialise = !(ns && atoi(ns) != 0) && !force_generic;
-  const int aot = any_expr ? SPEC_GENERIC : select_spec(e->P);
+  // a function with a per-window grid table needs the kernel instance that follows it
+  // (FixedSpec<Model, LIK, true>, mhx_kernels.hpp): compiled at run time, like every problem
+  // without an ahead-of-time kernel - the ahead-of-time ones stay what they were
+  bool any_wgrid = false;
+  for (int k = 0; k < e->P.K; ++k) {
+    FnDesc& f = e->P.fn[k];
+    const bool can = specialise && f.tgh != nullptr && f.model == MHX_MODEL_GAUSS_PEAKS &&
+                     f.shape[0] >= 1 && f.shape[0] <= 2 && f.shape[1] >= 1 && f.shape[1] <= 6 &&
+                     f.lik != MHX_LIK_EXPR;
+    if (!can) f.tgh = nullptr;  // (nobody would read it: the direct form everywhere, as before)
+    any_wgrid = any_wgrid || can;
+  }
+  const int aot = (any_expr || any_wgrid) ? SPEC_GENERIC : select_spec(e->P);
   e->rtc_note.clear();
   HIP_TRY(hipMemcpy(e->dP.p, &e->P, sizeof(ProblemDesc), hipMemcpyHostToDevice));
-  if (!any_expr && (aot != SPEC_GENERIC || !specialise)) {
+  if (!any_expr && !any_wgrid && (aot != SPEC_GENERIC || !specialise)) {
     e->spec = force_generic ? SPEC_GENERIC : aot;
     e->user_prog.reset();
   } else {
@@ -586,6 +651,7 @@ int finalize_problem(mhx_engine* e) {
           UserExpr u;
           u.builtin = type;
           u.lik = f.lik;
+          u.wgrid = f.tgh != nullptr;
           models.push_back(u);
         } else {
           builtin = true;  // stays with the generic dispatcher inside the compiled kernels
@@ -643,6 +709,29 @@ int finalize_problem(mhx_engine* e) {
       e->S.split_part = e->split_part.p;
     }
     HIP_TRY(hipMemset(e->split_pending.p, 0, (size_t)e->cfg.n_chains * sizeof(int32_t)));
+    // the per-chain split mode as ONE launch per portion of iterations (k_persist): the chain's
+    // master wave and its sweep workgroups hand each other the proposal and the partial sums
+    // through memory, which needs every workgroup of the launch on the GPU at once
+    // (MHX_NO_PERSIST=1: the two launches per iteration of rounds 1-3)
+    e->persist = false;
+    if (e->split_slices > 0 && !e->tsplit) {
+      const char* np_ = getenv("MHX_NO_PERSIST");
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus <= 0)
+        cus = 256;
+      const int64_t resident = (int64_t)cus * (e->fam->waves_per_group <= 8 ? 2 : 1);
+      const int64_t groups = e->cfg.n_chains * (1 + (int64_t)e->split_slices);
+      e->persist = !(np_ && atoi(np_) != 0) && groups * 10 <= resident * 9 && e->P.d <= 60;
+      if (e->persist) {
+        const size_t nm = 64 * (size_t)e->cfg.n_chains;
+        const size_t npb = 16 * (size_t)e->cfg.n_chains * e->P.K * (size_t)e->S.split_slots;
+        if ((e->persist_msg.n < nm && e->persist_msg.alloc(nm) != hipSuccess) ||
+            (e->persist_part.n < npb && e->persist_part.alloc(npb) != hipSuccess))
+          return fail(MHX_ENOMEM, "hipMalloc of the persistent kernel's handshake buffers failed");
+        e->S.persist_msg = e->persist_msg.p;
+        e->S.persist_part = e->persist_part.p;
+      }
+    }
   }
   // a name for what was chosen (mhx_kernel_name)
   static const char* kLik[] = {"normal", "normal_cutoff", "poisson", "expr"};
@@ -652,7 +741,8 @@ int finalize_problem(mhx_engine* e) {
     for (int k = 0; k < e->P.K; ++k) {
       const FnDesc& f = e->P.fn[k];
       const std::string t = f.model == MHX_MODEL_EXPR ? std::string("expr")
-                            : (f.user_slot >= 0 ? builtin_model_type(f) : std::string("generic"));
+                            : (f.user_slot >= 0 ? builtin_model_type(f) + (f.tgh ? "+wgrid" : "")
+                                                : std::string("generic"));
       e->kernel_name += (k ? ", " : "") + t + ":" + kLik[f.lik & 3];
     }
     e->kernel_name += "]";
@@ -661,7 +751,8 @@ int finalize_problem(mhx_engine* e) {
     if (!e->rtc_note.empty()) e->kernel_name += " [not specialised: " + e->rtc_note + "]";
   }
   if (e->split_slices > 0)
-    e->kernel_name += (e->tsplit ? " tsplit x" : " split x") + std::to_string(e->split_slices);
+    e->kernel_name += (e->tsplit ? " tsplit x" : (e->persist ? " persistent split x" : " split x")) +
+                      std::to_string(e->split_slices);
   e->problem_dirty = false;
   return MHX_OK;
 }
@@ -697,6 +788,11 @@ hipError_t do_split_step(mhx_engine* e, int mode, int plain) {
   return e->spec == SPEC_USER
              ? rtc_launch_split_step(*e->user_prog, e->stream, e->dP.p, e->S, e->R, mode, plain)
              : e->fam->split_step(e->spec, e->stream, e->dP.p, e->S, e->R, mode, plain);
+}
+hipError_t do_persist(mhx_engine* e, int64_t iters, int plain) {
+  return e->spec == SPEC_USER
+             ? rtc_launch_persist(*e->user_prog, e->stream, e->dP.p, e->S, e->R, e->split_slices, iters, plain)
+             : e->fam->persist(e->spec, e->stream, e->dP.p, e->S, e->R, e->split_slices, iters, plain);
 }
 hipError_t do_adaptive(mhx_engine* e, int64_t iters, int plain) {
   return e->spec == SPEC_USER
@@ -1047,7 +1143,17 @@ int launch_steps_enqueue(mhx_engine* e, int64_t iters, int plain) {
     if (rc != MHX_OK) return rc;
   }
   HIP_TRY(hipEventRecord(e->ev0, e->stream));
-  if (e->split_slices > 0) {
+  if (e->split_slices > 0 && e->persist) {
+    // persistent split mode: one launch, `iters` iterations (the kernel leaves its loop when no
+    // chain is running any more); the sync words start every launch at zero
+    // (launches of at most 2^22 iterations: what mhx_adaptive_advance asks for at most anyway)
+    for (int64_t left = iters; left > 0; left -= (int64_t)1 << 22) {
+      HIP_TRY(hipMemsetAsync(e->persist_msg.p, 0, e->persist_msg.n * sizeof(unsigned long long), e->stream));
+      HIP_TRY(hipMemsetAsync(e->persist_part.p, 0, e->persist_part.n, e->stream));
+      HIP_TRY(do_persist(e, std::min<int64_t>(left, (int64_t)1 << 22), plain));
+      e->launches += 1;
+    }
+  } else if (e->split_slices > 0) {
     // split mode: prime (first half of iteration 1), then per iteration the sweep over all
     // slices and the chain's own launch (second half + first half of the next; the last one
     // leaves nothing outstanding).  2 * iters + 1 small launches, queued without waiting.
@@ -1409,8 +1515,11 @@ int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y, cons
   // (PeaksModel, csrc/mhx_device.hpp).  Accepted when every x_i is within 8 ulp of max |x| of
   // x_0 + i h with h = (x_(n-1) - x_0) / (n - 1); MHX_NO_RECURRENCE=1 keeps the direct form.
   f.grid_H = 0.0;
+  f.tgh = nullptr;  // (per-window grids: finalize_problem)
+  D.n = n;
   {
     const char* nr = getenv("MHX_NO_RECURRENCE");
+    D.no_rec = nr && atoi(nr) != 0;
     if (!(nr && atoi(nr) != 0) && n >= 2 && std::isfinite(x[0]) && std::isfinite(x[n - 1])) {
       const double h = (x[n - 1] - x[0]) / (double)(n - 1);
       const double tol = 8.0 * 0x1p-52 * std::max(std::fabs(x[0]), std::fabs(x[n - 1]));

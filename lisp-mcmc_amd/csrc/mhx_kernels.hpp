@@ -34,6 +34,10 @@ struct GroupLds {
   unsigned long long tim[kWavesPerGroup][8], tlast[kWavesPerGroup];
 #endif
   int vote[4];  // "is any chain of the workgroup still running": three flags used in turn
+  // dealing the proposals of a workgroup to its wave slots by estimated cost (group_logpost)
+  int deal_cost[kWavesPerGroup];
+  double deal_ll[kWavesPerGroup];
+  int deal_skip;  // iterations the workgroup goes without looking at its costs (they were equal)
   double park[kWavesPerGroup][12];  // a ChainPark per wave: the chain's scalars during a sweep
   // the chain's position theta while a stepping kernel runs, for d <= kCurParams (beyond that it
   // is re-read from HBM): two L2 round trips less per iteration of a latency-bound single walker
@@ -65,6 +69,7 @@ __device__ __forceinline__ void lds_tables_begin() {
 }
 __device__ __forceinline__ void lds_begin(GroupLds& lds) {
   if (threadIdx.x == 0) lds.resident = 0;
+  if (threadIdx.x == 0) lds.deal_skip = 0;
   if (threadIdx.x < 4) lds.vote[threadIdx.x] = 0;
   lds_tables_begin();
   __syncthreads();
@@ -351,11 +356,37 @@ __device__ __forceinline__ double sweep_yw(const FnDesc& f, const typename Model
 // wave's own points differs, so a chain's bits never depend on which chains share its workgroup.
 // rmask (wave-uniform, 0 unless fast): the peaks that go by the uniform-grid recurrence this
 // step (PeaksModel, model_has_rec).
-template <class Model, int LIK>
-__device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::Prep& prep,
+template <bool B, class T, class F>
+struct PickType {
+  typedef T type;
+};
+template <class T, class F>
+struct PickType<false, T, F> {
+  typedef F type;
+};
+
+// WG: per-window grids (PeaksModel::regrid).  On a dataset that is not ONE grid every window
+// brings its own H = 64 h (FnDesc::tgh; 0: not a grid - that window takes the direct form), and
+// the grid constants of this sweep's copy of the chain's Prep follow it.  A compile-time choice
+// of the KERNEL (FixedSpec<Model, LIK, true>, which only run-time compiled kernels use: the
+// engine sends a problem with a per-window table to hiprtc, mhx_engine.cpp): with the constants
+// loop-carried the register allocator does visibly worse on the models of many peaks - as a
+// run-time flag of one instance config 3's kernel went from 36 to 266 scratch accesses in its
+// hot loops, as a second instance inside the same kernel from 74.8 to 104.5 ms per 20
+// iterations and config 2's by 3.5 % (same box) - and the datasets of one grid, or none, must
+// not pay for it.
+template <class Model, int LIK, bool WG = false>
+__device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::Prep& prep_in,
                                         bool active, GroupLds& lds, bool fast = false,
                                         unsigned rmask = 0u, bool bgrec = false) {
   constexpr int NARR = LIK == MHX_LIK_POISSON ? 2 : (LIK == MHX_LIK_NORMAL_CUTOFF ? 4 : 3);
+  constexpr bool kWinGrid = WG;
+  static_assert(!WG || (model_has_rec<Model>::value && model_has_skip<Model>::value), "regrid");
+  typename PickType<WG, typename Model::Prep, const typename Model::Prep&>::type prep = prep_in;
+  constexpr bool wgrid = WG;
+  double win_h = 0.0;   // lane i: H of window (wi & ~63) + i
+  double h_cur = 0.0;   // the H `prep` was last re-gridded for (0: prepare()'s, i.e. none)
+  (void)wgrid; (void)win_h; (void)h_cur;
   static_assert(kTilePoints == 2 * kThreads, "one double2 per thread per array per tile");
   const int l = lane_id();
   const int w = wave_in_group();
@@ -462,6 +493,29 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
       fastw = (tw & Model::kGuardBit) == 0u;
     }
     (void)tm;
+    if constexpr (kWinGrid) {
+      if (wgrid) {
+        if ((wi & 63) == 0) {
+          const int64_t ti = wi + l < nw ? wi + l : nw - 1;
+          win_h = f.tgh[ti];
+        }
+        const double hw = readlane_f64(win_h, (int)(wi & 63));
+        if (hw != 0.0) {
+          if (__double_as_longlong(hw) != __double_as_longlong(h_cur)) {  // (uniform; rare: runs of windows share their H)
+            Model::regrid(prep, hw);
+            h_cur = hw;
+          }
+          rmask = Model::rec_mask(prep);
+          bgrec = __builtin_amdgcn_readfirstlane((int)Model::rec_bg(prep)) != 0;
+          seed16 = Model::seed16(prep);
+          seed8 = Model::seed8(prep);
+        } else {  // not a grid: every evaluated peak directly
+          rmask = 0u;
+          bgrec = false;
+          seed16 = seed8 = 0u;
+        }
+      }
+    }
     auto tile_work = [&](auto fastc) {
       constexpr bool FAST = decltype(fastc)::value;
       // The lane's element of tile point 0 ... P-1 of each array, as LDS addresses the compiler
@@ -840,9 +894,25 @@ __device__ __forceinline__ double sweep_direct_rec(const FnDesc& f,
 }
 
 // A problem whose K functions all use one compiled model and likelihood
-template <class Model, int LIK>
+template <class Model, int LIK, bool WG = false>
 struct FixedSpec {
   static constexpr bool kSplit = true;  // has loglik_part
+  // proposals are dealt to wave slots by cost when the model's cost depends on the proposal
+  // (per-window peak masks and forms: group_logpost)
+#ifdef MHX_DEAL  // (off in the product build: see group_logpost, "DEALING")
+  static constexpr bool kDeal = model_has_skip<Model>::value;
+#else
+  static constexpr bool kDeal = false;
+#endif
+  template <class PF>
+  static __device__ __forceinline__ int cost(const FnDesc& f, PF pf, double* scratch) {
+    if constexpr (kDeal) {
+      typename Model::Prep prep = model_prepare<Model>(pf, f, scratch);
+      return Model::sweep_cost(prep, f);
+    } else {
+      return 0;
+    }
+  }
   // partial likelihood sum over points [p0, p1) (split mode; no barriers, one wave)
   template <class PF>
   static __device__ __forceinline__ double loglik_part(const FnDesc& f, PF pf, int64_t p0,
@@ -880,7 +950,7 @@ struct FixedSpec {
       rmask = may ? Model::rec_mask(prep) : 0u;
       bgrec = may && __builtin_amdgcn_readfirstlane((int)Model::rec_bg(prep)) != 0;
     }
-    return finish_lik<LIK>(f, sweep<Model, LIK>(f, prep, active, lds, fast, rmask, bgrec));
+    return finish_lik<LIK>(f, sweep<Model, LIK, WG>(f, prep, active, lds, fast, rmask, bgrec));
   }
   static __device__ __forceinline__ double logprior(const FnDesc&, const double*, double bt) {
     return bt;
@@ -890,6 +960,9 @@ struct FixedSpec {
 // Anything else: wave-uniform dispatch on (model, shape, likelihood)
 struct GenericSpec {
   static constexpr bool kSplit = false;  // models whose parameters live in LDS: batch kernels only
+  static constexpr bool kDeal = false;
+  template <class PF>
+  static __device__ __forceinline__ int cost(const FnDesc&, PF, double*) { return 0; }
   template <class PF>
   static __device__ __forceinline__ double loglik_part(const FnDesc&, PF, int64_t, int64_t, double*) {
     return 0.0;
@@ -1000,32 +1073,166 @@ __device__ __forceinline__ double bound_of(const FnDesc& f, const double* theta,
 }
 
 // theta' of this wave is in lds.prop[w]; collective over the workgroup
+//
+// DEALING.  The chains of a workgroup meet at a barrier every window of every sweep, and the four
+// waves of a SIMD share its issue slots: a sweep costs the sum over windows of the slowest SIMD's
+// load.  What a proposal costs is known before the sweep (Model::sweep_cost: which peaks each
+// window evaluates, and in which form), so the workgroup's proposals are dealt to its wave slots
+// by cost: ranked, then laid out in a snake over the SIMDs (rank 0-3 -> slots 0-3, rank 4-7 ->
+// slots 7-4, ...; slots s and s + 4 share a SIMD, slots 4 q .. 4 q + 3 sit on four different ones
+// - tools/microbench/wave_simd.hip: wave w of a workgroup runs on SIMD cyc[(k0 + w) % 4], cyc =
+// 0 2 1 3), which gives every SIMD one proposal of each quartile.  Wave slot s then JUDGES the
+// proposal of chain src(s) - likelihood sums only; the chain's identity, its scalars, its prior
+// and its accept test stay with the chain's own wave - and hands the sum back through LDS.  A
+// likelihood sum is a lane-strided accumulation and a butterfly inside ONE wave, the same
+// instructions whichever wave runs them: a chain's bits do not depend on the deal
+// (tests/test_gpu_families.py: MHX_NO_DEAL=1 against the default, bit for bit).
+// BUILT, MEASURED, AND LEFT OUT OF THE PRODUCT BUILD (round 4; -DMHX_DEAL compiles it in).  What
+// it costs: the estimate (a second prepare() and one pass of tile_mask) and one barrier - so a
+// workgroup that finds its costs within a quarter of one another leaves everything in place and
+// does not look again for 15 iterations (deal_skip).  Same-box A/B against the build without it,
+// 3-5 interleaved rounds of bench.py each (kernel time of the timed launch): config 2 at the
+// driver's arguments (a walk's iterations 6-25, wild proposals) 2.888 against 2.896 ms (+0.3 %;
+// dealing at every iteration +1.2 %, and +3.8 % with the recurrence off, where a directly
+// evaluated peak costs 14 instructions per point), but config 2 after the first adaptation tick
+// 29.52 against 29.09 ms (-1.5 %) and config 3 75.17 against 73.49 ms (-2.3 %) - with
+// MHX_NO_DEAL=1 as well: it is the code in the kernel (registers live across the first barrier,
+// 220 more instructions per iteration in the controller), not the dealing, that costs there.
+// The model that priced this (-3.8 % in the driver's window) was right about
+// the gross gain; the cost estimate eats most of it.
 template <class Spec>
 __device__ __forceinline__ double group_logpost(const ProblemDesc& P, bool active, GroupLds& lds,
                                                 int w, double* ll_out, double* lp_out) {
-  __syncthreads();  // proposals written, previous users of the tile buffers are done
+  bool deal = false;
+  int skip = 0;
+  if constexpr (Spec::kDeal) {
+    deal = __builtin_amdgcn_readfirstlane(P.no_deal) == 0;
+    // (written by thread 0 behind the first barrier of an earlier call: the barriers of that
+    // call's sweep lie in between)
+    skip = deal ? __builtin_amdgcn_readfirstlane(*(volatile int*)&lds.deal_skip) : 0;
+    deal = deal && skip == 0;
+    if (deal) {
+      // (the wave's own proposal: written by this wave, no barrier needed to read it back)
+      __builtin_amdgcn_wave_barrier();
+      int cost = 0;
+      if (active) {
+        const double* tho = lds.prop[w];
+        for (int k = 0; k < P.K; ++k) {
+          const FnDesc& f = P.fn[k];
+          auto pfo = [&](int j) -> double { return tho[f.idx[j]]; };
+          cost += Spec::cost(f, pfo, lds.prm[w]);
+        }
+        cost = cost < 1 ? 1 : cost;  // (0 stands for "no proposal")
+      }
+      if (lane_id() == 0) lds.deal_cost[w] = cost;
+    }
+  }
+  __syncthreads();  // proposals (and their costs) written, previous users of the tile buffers are done
   MHX_TIM(lds, 1);
+  int src = w;
+  bool act = active;
+  if constexpr (Spec::kDeal) {
+    if (deal) {
+      static_assert(kWavesPerGroup % 4 == 0 && kWavesPerGroup <= 32, "snake over four SIMDs");
+      const int l = lane_id();
+      const int mine = l < kWavesPerGroup ? lds.deal_cost[l] : 0;
+      int rank = 0;  // lane c: how many proposals of the workgroup cost more than chain c's
+      int cmax = 0, cmin = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < kWavesPerGroup; ++j) {
+        const int cj = __builtin_amdgcn_readlane(mine, j);
+        rank += (cj > mine || (cj == mine && j < l)) ? 1 : 0;
+        cmax = cj > cmax ? cj : cmax;
+        cmin = (cj != 0 && cj < cmin) ? cj : cmin;
+      }
+      // every proposal within a quarter of the cheapest: nothing to gain, everybody stays at home
+      const bool level = cmax - cmin <= (cmin >> 2);
+      if (threadIdx.x == 0) lds.deal_skip = level ? 15 : 0;
+      deal = !level;
+      if (deal) {
+        const int q = rank >> 2, p = rank & 3;
+        const int slot = 4 * q + ((q & 1) ? 3 - p : p);
+        const unsigned long long hit = __ballot(l < kWavesPerGroup && slot == w);
+        src = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hit));
+        act = __builtin_amdgcn_readlane(mine, src) != 0;
+      }
+    } else if (skip > 0) {
+      if (threadIdx.x == 0) lds.deal_skip = skip - 1;
+    }
+  }
   double ll = 0.0, lp = 0.0;
-  const double* th = lds.prop[w];
+  const double* th = lds.prop[src];   // the proposal this wave judges
+  const double* tho = lds.prop[w];    // ... and its own chain's (the prior stays at home)
   for (int k = 0; k < P.K; ++k) {
     const FnDesc& f = P.fn[k];
     auto pf = [&](int j) -> double { return th[f.idx[j]]; };
-    const double v = Spec::loglik(f, pf, active, lds, lds.prm[w]);
+    const double v = Spec::loglik(f, pf, act, lds, lds.prm[w]);
     ll = k == 0 ? v : ll + v;
     // Spec::logprior lets a user prior body add terms to bounds-total (M:366-369)
-    const double q = Spec::logprior(f, th, logprior_fn(f, th));
+    const double q = Spec::logprior(f, tho, logprior_fn(f, tho));
     lp = k == 0 ? q : lp + q;
+  }
+  if constexpr (Spec::kDeal) {
+    if (deal) {
+      if (lane_id() == 0) lds.deal_ll[src] = ll;
+      __syncthreads();
+      ll = *(volatile double*)&lds.deal_ll[w];
+    }
   }
   *ll_out = ll;
   *lp_out = lp;
   return ll + lp;
 }
 
+// PERSIST (with SPLIT): the chain's master wave of k_persist - wave 0 of workgroup (0, chain) -
+// runs whole iterations in ONE launch: where the split step kernel leaves the proposal behind and
+// ends, it publishes it (persist_publish) and goes on with the second half of the iteration,
+// whose split_logpost waits for the partial sums of the chain's sweep workgroups.
+// The handshake moves 8 ... 63 parameters one way and a few hundred partial sums the other, once
+// per iteration, between XCDs whose L2s do not see each other's lines.  Acquire / release at
+// agent scope would do - and invalidate the whole L2 of the reader at every poll, the dataset
+// with it (measured: 18 us per step where the two launches take 16).  Instead every word of the
+// handshake is written and read by memory instructions that go to the level all XCDs share (sc1:
+// relaxed agent-scope atomics, and 16-byte loads / stores with the same cache policy), data and
+// tag in ONE naturally aligned unit - a 128-byte line of the proposal block, a 16-byte {sum,
+// generation} pair - so that who finds the tag finds the data, and nothing else leaves a cache.
+constexpr unsigned long long kPersistStop = 1ull << 62;  // tag: the chain's master is through
+constexpr unsigned kPersistPatience = 1u << 20;   // polls (a memory round trip apart) before giving up
+constexpr int kPersistMaxParams = 60;             // four lines of 15 parameters and a tag
+typedef __attribute__((ext_vector_type(4))) unsigned int persist_u4;
+__device__ __forceinline__ void persist_store_pair(void* p, double v, unsigned long long tag) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const persist_u4 q = {(unsigned)b, (unsigned)(b >> 32), (unsigned)tag, (unsigned)(tag >> 32)};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(q) : "memory");
+}
+__device__ __forceinline__ persist_u4 persist_load_pair(const void* p) {
+  persist_u4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+               : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+// the proposal (lane j < d: theta'_j) and its generation into the chain's block
+__device__ __forceinline__ void persist_publish(const ChainState& S, int64_t c, int d, double thp,
+                                                unsigned long long gen) {
+  unsigned long long* m = S.persist_msg + c * 64;
+  const int l = lane_id();
+  if (l < d)
+    __hip_atomic_store(m + (l / 15) * 16 + l % 15, (unsigned long long)__double_as_longlong(thp),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the parameters first, then the tags
+  if ((l & 15) == 15)
+    __hip_atomic_store(m + l, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // split mode: the same value from the partial sums the sweep launch left in S.split_part
-template <class Spec>
+// PERSIST (k_persist's master wave): the partial sums arrive as {sum, generation} pairs in
+// S.persist_part while this waits - every slot's pair is read until it carries generation `gen`;
+// a slot that never does (patience) makes the sum a NaN, which freezes the chain.
+template <class Spec, bool PERSIST = false>
 __device__ __forceinline__ double split_logpost(const ProblemDesc& P, const ChainState& S,
                                                 int64_t c, bool active, GroupLds& lds, int w,
-                                                double* ll_out, double* lp_out) {
+                                                double* ll_out, double* lp_out,
+                                                unsigned long long gen = 0) {
   double ll = 0.0, lp = 0.0;
   const double* th = lds.prop[w];
   const int l = lane_id();
@@ -1033,6 +1240,31 @@ __device__ __forceinline__ double split_logpost(const ProblemDesc& P, const Chai
     const FnDesc& f = P.fn[k];
     const double* part = S.split_part + ((active ? c : 0) * P.K + k) * S.split_slots;
     double a = 0.0;
+    if constexpr (PERSIST) {
+      const char* pairs = (const char*)S.persist_part + (((active ? c : 0) * P.K + k) * S.split_slots) * 16;
+      bool lost = false;
+      for (int s0 = 0; s0 < S.split_slots && active; s0 += kWave) {  // (uniform)
+        const int sl = s0 + l;
+        double v = 0.0;
+        unsigned n = 0;
+        for (;;) {
+          bool have = true;
+          if (sl < S.split_slots) {
+            const persist_u4 q = persist_load_pair(pairs + (size_t)sl * 16);
+            have = (((unsigned long long)q.w << 32) | q.z) == gen;
+            v = __longlong_as_double((long long)(((unsigned long long)q.y << 32) | q.x));
+          }
+          if (__builtin_amdgcn_readfirstlane((int)(__ballot(!have) == 0ull))) break;
+          if (++n >= kPersistPatience) {
+            lost = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (sl < S.split_slots) a = a + v;  // slot order per lane, as below
+      }
+      if (lost) a = __builtin_nan("");
+    } else
     for (int s = l; s < S.split_slots; s += kWave) a = a + part[s];  // slot order, fixed
     const double v = finish_by_lik(f, wave_sum(a));
     ll = k == 0 ? v : ll + v;
@@ -1249,7 +1481,7 @@ __device__ __forceinline__ void k_step_injected_body(
     const ProblemDesc* __restrict__ Pp, ChainState S, const double* __restrict__ Lin,
     int per_chain_l, const double* __restrict__ z, const double* __restrict__ u,
     const double* __restrict__ T, unsigned char* __restrict__ accepted);
-template <class Spec, bool SPLIT = false>
+template <class Spec, bool SPLIT = false, bool PERSIST = false>
 __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ Pp, ChainState S,
                                                 RunDesc R, int64_t max_iters, int plain,
                                                 int mode = 1);
@@ -1540,16 +1772,18 @@ __global__ __launch_bounds__(kThreads, 4) void k_adaptive(const ProblemDesc* __r
 // sweep launch: mode 1, 2) and / or the first half of the next (end test, shut-down test, new
 // proposal into S.split_prop: mode 0, 1).  mode 0 primes, 1 is the steady state, 2 ends a run
 // of launches with nothing outstanding.
-template <class Spec, bool SPLIT>
+template <class Spec, bool SPLIT, bool PERSIST>
 __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ Pp, ChainState S,
                                                 RunDesc R, int64_t max_iters, int plain,
                                                 int mode) {
+  static_assert(SPLIT || !PERSIST, "the persistent kernel is a split-mode kernel");
   GroupLds& lds = *reinterpret_cast<GroupLds*>(mhx_lds_raw);
   lds_begin(lds);
   const ProblemDesc& P = *Pp;
   const int w = wave_in_group(), l = lane_id(), d = P.d;
   // wave slot -> chain (ChainState::slot_chain: the chains still walking, packed)
-  const int64_t slot = (int64_t)blockIdx.x * kWavesPerGroup + w;
+  // (PERSIST: the one wave of this workgroup that got here is the master of chain blockIdx.y)
+  const int64_t slot = PERSIST ? (int64_t)blockIdx.y : (int64_t)blockIdx.x * kWavesPerGroup + w;
   const bool in_range = slot < (S.slot_chain ? S.n_slots : S.n_chains);
   const int64_t mapped =
       in_range && S.slot_chain ? (int64_t)__builtin_amdgcn_readfirstlane(S.slot_chain[slot]) : slot;
@@ -1578,7 +1812,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
   }
 #endif
 
-  for (int64_t it = 0; SPLIT || it < max_iters; ++it) {
+  for (int64_t it = 0; (SPLIT && !PERSIST) || it < max_iters; ++it) {
     MHX_TIM(lds, 6);
     MHX_TIMC(lds, 7);
     const int l = lane_id();  // (formed per iteration: see lane_id())
@@ -1601,7 +1835,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     bool running = valid && r.status == MHX_CHAIN_RUNNING;
     double thp = 0.0, u = 1.0;
     bool resumed = false;
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT && !PERSIST) {
       resumed = it == 0 && mode != 0;
       if (!resumed && (it > 1 || (it > 0 && mode == 2))) break;
     }
@@ -1675,7 +1909,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
       if (l < d) lds.prop[w][l] = thp;
       MHX_TIMC(lds, 2);
     }
-    if constexpr (SPLIT) {  // hand the proposal to the sweep launch and stop here
+    if constexpr (SPLIT && !PERSIST) {  // hand the proposal to the sweep launch and stop here
       if (running) {
         if (l < d) S.split_prop[c * d + l] = thp;
         if (l == 0) {
@@ -1684,6 +1918,9 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
         }
       }
       break;
+    }
+    if constexpr (PERSIST) {  // ... to the chain's sweep workgroups of this same launch
+      if (running) persist_publish(S, c, d, thp, (unsigned long long)(it + 1));
     }
     }  // !resumed
     double ll, lp;
@@ -1701,7 +1938,10 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
 #ifndef MHX_NO_PARK  // (build knob for A/B measurements)
     if constexpr (!SPLIT) chain_park(slot, r, u, t_next);
 #endif
-    if constexpr (SPLIT)
+    if constexpr (PERSIST)
+      prob1 = split_logpost<Spec, true>(P, S, c, running, lds, w, &ll, &lp,
+                                        (unsigned long long)(it + 1));
+    else if constexpr (SPLIT)
       prob1 = split_logpost<Spec>(P, S, c, running, lds, w, &ll, &lp);
     else
       prob1 = group_logpost<Spec>(P, running, lds, w, &ll, &lp);
@@ -1899,6 +2139,82 @@ __global__ __launch_bounds__(kThreads) void k_split_step(const ProblemDesc* __re
                                                          ChainState S, RunDesc R, int mode,
                                                          int plain) {
   k_adaptive_body<Spec, true>(Pp, S, R, 1, plain, mode);
+}
+
+// PERSISTENT split mode: a handful of chains (fewer than a workgroup's worth) on long datasets, the
+// reference's own way of working (test.lisp:12-24 fits ONE walker).  The two-launch split mode
+// pays two kernel launches and a dozen dependent global round trips per iteration - 16 us per
+// step on 1e5 points, 5 of them arithmetic.  Here ONE launch runs max_iters iterations: grid
+// (1 + slices, chains) workgroups, all of them resident at once (the host checks); workgroup
+// (0, c) keeps only its wave 0, the chain's master, which runs the controller of
+// k_adaptive_body; workgroups (1 .., c) are the chain's sweep workgroups, wave w of workgroup g the
+// slot (g - 1) * waves + w of k_split_sweep - same slots, same points, same order of the sum: the
+// same bits as the two-launch mode.  Per iteration: the master publishes the proposal and a
+// generation number (release, agent scope), the sweep workgroups - polling it - compute their
+// partial sums and count themselves in (a fence and one atomic per workgroup), the master -
+// polling that count - judges the proposal.  Every poll loop gives up after kPersistPatience
+// polls (the master then freezes the chain and raises the stop word, which ends the sweep
+// workgroups): no wave can spin for ever.
+template <class Spec>
+__device__ __forceinline__ void k_persist_body(const ProblemDesc* __restrict__ Pp, ChainState S,
+                                               RunDesc R, int64_t max_iters, int plain) {
+  const int64_t c = blockIdx.y;
+  if (blockIdx.x == 0) {
+    if (wave_in_group() != 0) return;  // (s_barrier counts the waves still alive)
+    k_adaptive_body<Spec, true, true>(Pp, S, R, max_iters, plain, 1);
+    persist_publish(S, c, 0, 0.0, kPersistStop);
+    return;
+  }
+  SweepLds& sl = *reinterpret_cast<SweepLds*>(mhx_lds_raw);
+  const ProblemDesc& P = *Pp;
+  const int w = wave_in_group(), l = lane_id(), d = P.d;
+  lds_tables_begin();
+  __syncthreads();
+  const int slot = ((int)blockIdx.x - 1) * kWavesPerGroup + w;
+  const unsigned long long* msg = S.persist_msg + c * 64;
+  const int nlines = (d + 14) / 15;  // lines of the block that carry parameters
+  for (unsigned long long it = 0;; ++it) {
+    // the master's next word: the proposal of generation it + 1, or stop.  Every wave polls for
+    // itself (no barrier in this loop: the waves of a sweep workgroup run independently).
+    unsigned long long q = 0;
+    bool ok = false;
+    for (unsigned n = 0; n < kPersistPatience; ++n) {
+      q = __hip_atomic_load(msg + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool is_tag = (l & 15) == 15 && (l >> 4) < nlines;
+      const unsigned long long stale = __ballot(is_tag && q <= it);
+      if (__builtin_amdgcn_readfirstlane((int)(stale == 0ull))) {
+        ok = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const unsigned long long tag0 =
+        ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(q >> 32), 15) << 32) |
+        (unsigned)__builtin_amdgcn_readlane((int)q, 15);
+    if (!ok || (tag0 & kPersistStop)) return;
+    if ((l & 15) != 15 && (l >> 4) < nlines)
+      sl.prop[w][(l >> 4) * 15 + (l & 15)] = __longlong_as_double((long long)q);
+    __builtin_amdgcn_wave_barrier();
+    const double* th = sl.prop[w];
+    for (int k = 0; k < P.K; ++k) {
+      const FnDesc& f = P.fn[k];
+      auto pf = [&](int j) -> double { return th[f.idx[j]]; };
+      const int64_t pairs = (f.n + 2 * kWave - 1) / (2 * kWave);
+      const int64_t per = (pairs + S.split_slots - 1) / S.split_slots;
+      const int64_t b0 = (int64_t)slot * per, b1 = b0 + per < pairs ? b0 + per : pairs;
+      double v = 0.0;
+      if (b0 < b1) v = Spec::loglik_part(f, pf, b0 * 2 * kWave, b1 * 2 * kWave, sl.scr[w]);
+      if (l == 0)
+        persist_store_pair((char*)S.persist_part + (((size_t)c * P.K + k) * S.split_slots + slot) * 16, v,
+                           it + 1);
+    }
+  }
+}
+template <class Spec>
+__global__ __launch_bounds__(kThreads) void k_persist(const ProblemDesc* __restrict__ Pp,
+                                                      ChainState S, RunDesc R, int64_t max_iters,
+                                                      int plain) {
+  k_persist_body<Spec>(Pp, S, R, max_iters, plain);
 }
 
 // Initial L of M:896-901 when the caller gave none.

@@ -65,6 +65,10 @@ struct Family {
                              const ChainState& S, int n_slices);
   hipError_t (*split_step)(int spec, hipStream_t st, const ProblemDesc* P, const ChainState& S,
                            const RunDesc& R, int mode, int plain);
+  // ... or ONE launch for many iterations of a handful of chains (k_persist): grid (1 + slices,
+  // chains), every workgroup resident at once (the caller checks)
+  hipError_t (*persist)(int spec, hipStream_t st, const ProblemDesc* P, const ChainState& S,
+                        const RunDesc& R, int slices, int64_t max_iters, int plain);
 };
 
 const Family& family_w8();

@@ -218,20 +218,38 @@ static std::string generate(const std::vector<UserExpr>& models,
         << "    return (double)(" << u.lik_expr << ");\n  }\n";
     s << "};\n";
   }
+  static const char* kLikName[] = {"MHX_LIK_NORMAL", "MHX_LIK_NORMAL_CUTOFF", "MHX_LIK_POISSON",
+                                   "MHX_LIK_EXPR"};
+  // dealing the workgroup's proposals by cost (group_logpost): for the functions whose model is
+  // an ahead-of-time struct with per-window peak masks
+  std::ostringstream deal_any, deal_cases;
+  deal_any << "false";
+  for (size_t m = 0; m < models.size(); ++m) {
+    const int lik = models[m].lik;
+    if (!models[m].builtin.empty() && lik >= 0 && lik <= 2) {
+      const char* wg = models[m].wgrid ? ", true" : "";
+      deal_any << " || FixedSpec<UserModel" << m << ", " << kLikName[lik] << wg << ">::kDeal";
+      deal_cases << "      case " << m << ": return FixedSpec<UserModel" << m << ", " << kLikName[lik]
+                 << wg << ">::cost(f, pf, scratch);\n";
+    }
+  }
   s << "struct UserSpec {\n"
+       "  static constexpr bool kDeal = " << deal_any.str() << ";\n"
+       "  template <class PF>\n"
+       "  static __device__ __forceinline__ int cost(const FnDesc& f, PF pf, double* scratch) {\n"
+       "    switch (f.user_slot) {\n" << deal_cases.str() <<
+       "      default: (void)pf; (void)scratch; return 0;\n    }\n  }\n"
        "  template <class PF>\n"
        "  static __device__ __forceinline__ double loglik(const FnDesc& f, PF pf, bool active,\n"
        "                                                  GroupLds& lds, double* scratch) {\n"
        "    switch (f.user_slot) {\n";
   // a slot belongs to one function, whose likelihood is known now: only that sweep is compiled
-  static const char* kLikName[] = {"MHX_LIK_NORMAL", "MHX_LIK_NORMAL_CUTOFF", "MHX_LIK_POISSON",
-                                   "MHX_LIK_EXPR"};
   for (size_t m = 0; m < models.size(); ++m) {
     const int lik = models[m].lik;
     if (!models[m].builtin.empty() && lik >= 0 && lik <= 2)
       // the whole FixedSpec: fast-path vote, tile-level peak skipping, parameters in SGPRs
       s << "      case " << m << ": return FixedSpec<UserModel" << m << ", " << kLikName[lik]
-        << ">::loglik(f, pf, active, lds, scratch);\n";
+        << (models[m].wgrid ? ", true" : "") << ">::loglik(f, pf, active, lds, scratch);\n";
     else if (lik >= 0 && lik <= 3)
       s << "      case " << m << ": return GenericSpec::one_lik<UserModel" << m << ", "
         << kLikName[lik] << ">(f, pf, active, lds);\n";
@@ -297,7 +315,10 @@ static std::string generate(const std::vector<UserExpr>& models,
          "  k_split_tsweep_body<UserSpec>(P, slices, S, n_slices);\n}\n"
          "extern \"C\" __global__ __launch_bounds__(MHX_USER_THREADS) void mhx_user_split_step(\n"
          "    const ProblemDesc* P, ChainState S, RunDesc R, int mode, int plain) {\n"
-         "  k_adaptive_body<UserSpec, true>(P, S, R, 1, plain, mode);\n}\n";
+         "  k_adaptive_body<UserSpec, true>(P, S, R, 1, plain, mode);\n}\n"
+         "extern \"C\" __global__ __launch_bounds__(MHX_USER_THREADS) void mhx_user_persist(\n"
+         "    const ProblemDesc* P, ChainState S, RunDesc R, int64_t max_iters, int plain) {\n"
+         "  k_persist_body<UserSpec>(P, S, R, max_iters, plain);\n}\n";
   return s.str();
 }
 
@@ -504,12 +525,17 @@ static int build_once(const std::vector<UserExpr>& models, const std::vector<Use
     if (he == hipSuccess)
       he = hipFuncSetAttribute(reinterpret_cast<const void*>(prog->f_split_step),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)fam.lds_bytes);
+    if (he == hipSuccess)
+      he = hipModuleGetFunction(&prog->f_persist, prog->module, "mhx_user_persist");
+    if (he == hipSuccess)
+      he = hipFuncSetAttribute(reinterpret_cast<const void*>(prog->f_persist),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)fam.lds_bytes);
     if (he != hipSuccess) {
       *err = std::string("split-mode module functions: ") + hipGetErrorString(he);
       return -1;
     }
     if (static_lds(prog->f_split_sweep) != 0 || static_lds(prog->f_split_step) != 0 ||
-        static_lds(prog->f_split_tsweep) != 0) {
+        static_lds(prog->f_split_tsweep) != 0 || static_lds(prog->f_persist) != 0) {
       *err = "split-mode module functions have static LDS";
       return -1;
     }
@@ -627,6 +653,16 @@ hipError_t rtc_launch_split_step(const UserProgram& p, hipStream_t st, const Pro
   RunDesc r = R;
   void* args[] = {(void*)&P, (void*)&s, (void*)&r, (void*)&mode, (void*)&plain};
   return hipModuleLaunchKernel(p.f_split_step, grid_for(p, S.slot_chain ? S.n_slots : S.n_chains), 1, 1,
+                               (unsigned)p.fam->threads, 1, 1, (unsigned)p.fam->lds_bytes, st, args,
+                               nullptr);
+}
+hipError_t rtc_launch_persist(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                              const ChainState& S, const RunDesc& R, int slices, int64_t max_iters,
+                              int plain) {
+  ChainState s = S;
+  RunDesc r = R;
+  void* args[] = {(void*)&P, (void*)&s, (void*)&r, (void*)&max_iters, (void*)&plain};
+  return hipModuleLaunchKernel(p.f_persist, 1u + (unsigned)slices, (unsigned)S.n_chains, 1,
                                (unsigned)p.fam->threads, 1, 1, (unsigned)p.fam->lds_bytes, st, args,
                                nullptr);
 }

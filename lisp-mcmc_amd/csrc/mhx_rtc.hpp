@@ -24,6 +24,8 @@ struct UserExpr {
   std::string builtin;   // models: non-empty = the C++ type of an ahead-of-time model struct
                          // ("PeaksModel<1, 3, false>"): no expression, the function is only
                          // given its own compile-time specialisation
+  bool wgrid = false;    // builtin peaks models: the function has a per-window grid table
+                         // (FnDesc::tgh) - its kernel is FixedSpec<Model, LIK, true>
   int lik = -1;          // models: the function's likelihood kind (-1: dispatch at run time)
   std::string lik_expr;  // models with MHX_LIK_EXPR: the per-point term over y, model, error
 };
@@ -33,6 +35,7 @@ struct UserProgram {
   hipFunction_t f_logpost = nullptr, f_init = nullptr, f_step = nullptr, f_adaptive = nullptr;
   hipFunction_t f_split_sweep = nullptr, f_split_step = nullptr;  // only with has_split
   hipFunction_t f_split_tsweep = nullptr;                         // (the tile-sliced sweep)
+  hipFunction_t f_persist = nullptr;                              // (the persistent split kernel)
   bool has_split = false;
   const Family* fam = nullptr;  // the kernel family (workgroup shape) the module was built for
   std::string source, log;
@@ -87,5 +90,8 @@ hipError_t rtc_launch_split_step(const UserProgram& p, hipStream_t st, const Pro
 hipError_t rtc_launch_adaptive(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                                const ChainState& S, const RunDesc& R, int64_t max_iters,
                                int plain);
+hipError_t rtc_launch_persist(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                              const ChainState& S, const RunDesc& R, int slices, int64_t max_iters,
+                              int plain);
 
 }  // namespace mhx

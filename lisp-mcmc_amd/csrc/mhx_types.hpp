@@ -56,10 +56,16 @@ struct FnDesc {
   int32_t prior_slot; // >= 0: index of the run-time compiled prior body, else -1
   int32_t no_yw;      // 1: never take the two-array "yw" tiles of the all-recurrence steps (MHX_NO_YW=1)
   int32_t pad_;
+  // per-window grids: [ceil(n / kPadPoints)] 64 h of every 2048-point window whose x are a grid
+  // x_w + i h (to 8 ulp of its max |x|), 0 where they are not; nullptr when the WHOLE dataset is
+  // one grid (grid_H != 0) or no window is.  Runs of windows on one grid carry the same bits.
+  const double* tgh;
 };
 
 struct ProblemDesc {
   int32_t d, K;
+  int32_t no_deal;  // 1: wave w judges the proposal of its own chain (MHX_NO_DEAL=1; group_logpost)
+  int32_t pad_;
   FnDesc fn[MHX_MAX_FUNCTIONS];
 };
 
@@ -111,6 +117,15 @@ struct ChainState {
   const int32_t* slot_chain;
   int64_t n_slots;  // entries of slot_chain
   int32_t split_pad_;
+  // persistent split mode (k_persist: ONE launch runs many iterations of a handful of chains
+  // spread over the GPU); both zeroed by the host before every launch
+  // persist_msg [C][64] 64-bit words: the chain's proposal as four 128-byte lines of 15
+  // parameters and one generation tag each (element j at word (j / 15) * 16 + j % 15, tags at
+  // words 15, 31, 47, 63); persist_part [C][K][split_slots] 16-byte pairs {partial sum,
+  // generation}.  A 128-byte line / a 16-byte pair is written and read by ONE memory
+  // instruction that goes to the level every XCD sees (sc1): who finds the tag finds the data.
+  unsigned long long* persist_msg;
+  void* persist_part;
 };
 
 struct RunDesc {

@@ -572,6 +572,33 @@ static double mir_grid_H(const orc_fn* f) {
   return 64.0 * h;
 }
 
+/* csrc/mhx_engine.cpp, finalize_problem ("Per-window grids"): on a dataset that is not ONE grid,
+ * window w (2048 points) gets H_w = 64 h when its data points are x_first + i h to 8 ulp of the
+ * window's max |x| - tried with the previous grid window's h first, then with its own
+ * (x_last - x_first) / (points - 1) - and 0 otherwise.  *h_prev carries the last accepted h. */
+static int mir_no_window_grids = 0; /* orc_mirror_set_window_grids(0): MHX_NO_WINDOW_GRIDS=1's twin */
+void orc_mirror_set_window_grids(int on) { mir_no_window_grids = !on; }
+static int mir_window_fits(const double* xw, size_t cnt, double h, double tol) {
+  if (h == 0.0 || !isfinite(h)) return 0;
+  for (size_t i = 0; i < cnt; ++i)
+    if (!(fabs(xw[i] - (xw[0] + (double)i * h)) <= tol)) return 0;
+  return 1;
+}
+static double mir_window_H(const orc_fn* f, size_t base, size_t win, double* h_prev) {
+  if (mir_no_recurrence || mir_no_window_grids || f->n < 2) return 0.0;
+  const size_t cnt = f->n - base < win ? f->n - base : win;
+  if (cnt < 2) return 0.0;
+  const double* xw = f->x + base;
+  if (!isfinite(xw[0]) || !isfinite(xw[cnt - 1])) return 0.0;
+  const double a0 = fabs(xw[0]), a1 = fabs(xw[cnt - 1]);
+  const double tol = 8.0 * 0x1p-52 * (a0 > a1 ? a0 : a1);
+  double h = *h_prev;
+  if (!mir_window_fits(xw, cnt, h, tol)) h = (xw[cnt - 1] - xw[0]) / (double)(cnt - 1);
+  if (!mir_window_fits(xw, cnt, h, tol)) return 0.0;
+  *h_prev = h;
+  return 64.0 * h;
+}
+
 /* csrc/mhx_device.hpp: mexp2_negsq_safe = mexp2(max(-(t t), -1100)), the guarded form a chain
  * uses for a function whose parameters put |t| beyond kFastT somewhere in the data range */
 static double mir_exp2_negsq_safe(double t) {
@@ -677,27 +704,39 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
   const double gH = mir_grid_H(f);
   double rm2d[MHX_MAX_FN_PARAMS], rnd2[MHX_MAX_FN_PARAMS], rq[MHX_MAX_FN_PARAMS];
   int rec[MHX_MAX_FN_PARAMS], s16[MHX_MAX_FN_PARAMS], s8[MHX_MAX_FN_PARAMS];
-  for (int k = 0; k < npk; ++k) {
-    const double dl = gH * iw[k];
-    rm2d[k] = -2.0 * dl;
-    rnd2[k] = -(dl * dl);
-    rq[k] = mir_mexp2(2.0 * rnd2[k]);
-    /* three classes by width (PeaksModel::prepare): S |D| <= 1 for the seeding period S = 32, 16
-     * or 8 points of a lane; a peak of a shorter class is re-seeded inside the window too */
-    const int base = (fast || has_skip) && gH != 0.0;
-    const int ok32 = base && (fabs(dl) * (double)MIR_SEED_STEPS <= 1.0);
-    const int multi = npk <= 2; /* PeaksModel::kMultiSeed: models of at most two peaks */
-    const int ok16 = multi ? base && (fabs(dl) * (double)(MIR_SEED_STEPS / 2) <= 1.0) : ok32;
-    const int ok8 = multi ? base && (fabs(dl) * (double)(MIR_SEED_STEPS / 4) <= 1.0) : ok32;
-    rec[k] = ok8;
-    s16[k] = ok8 && !ok32;
-    s8[k] = ok8 && !ok16;
-  }
-  /* ... and when EVERY peak goes by the recurrence, a constant or linear background does too
-   * (Prep::bgrec): b(x + 64 h) = b(x) + 64 h b1, re-seeded with the peaks */
-  int bgrec = nbg >= 1 && nbg <= 2 && npk <= 2; /* (PeaksModel::prepare: at most two peaks) */
-  for (int k = 0; k < npk; ++k) bgrec = bgrec && rec[k];
-  const double bgH = nbg == 2 ? local[1] * gH : 0.0;
+  int bgrec = 0;
+  double bgH = 0.0;
+  /* PeaksModel::prepare (H = the dataset's grid_H) and PeaksModel::regrid (H = the window's own,
+   * on datasets that are not one grid: sweep(), "Per-window grids"): the same operations */
+#define MIR_SET_GRID(H)                                                                         \
+  do {                                                                                          \
+    for (int k = 0; k < npk; ++k) {                                                             \
+      const double dl = (H) * iw[k];                                                            \
+      rm2d[k] = -2.0 * dl;                                                                      \
+      rnd2[k] = -(dl * dl);                                                                     \
+      rq[k] = mir_mexp2(2.0 * rnd2[k]);                                                         \
+      /* three classes by width: S |D| <= 1 for the seeding period S = 32, 16 or 8 points of a  \
+       * lane; a peak of a shorter class is re-seeded inside the window too */                  \
+      const int base = (fast || has_skip) && (H) != 0.0;                                        \
+      const int ok32 = base && (fabs(dl) * (double)MIR_SEED_STEPS <= 1.0);                      \
+      const int multi = npk <= 2; /* PeaksModel::kMultiSeed: models of at most two peaks */     \
+      const int ok16 = multi ? base && (fabs(dl) * (double)(MIR_SEED_STEPS / 2) <= 1.0) : ok32; \
+      const int ok8 = multi ? base && (fabs(dl) * (double)(MIR_SEED_STEPS / 4) <= 1.0) : ok32;  \
+      rec[k] = ok8;                                                                             \
+      s16[k] = ok8 && !ok32;                                                                    \
+      s8[k] = ok8 && !ok16;                                                                     \
+    }                                                                                           \
+    /* ... and when EVERY peak goes by the recurrence, a constant or linear background does too \
+     * (Prep::bgrec): b(x + 64 h) = b(x) + 64 h b1, re-seeded with the peaks */                 \
+    bgrec = nbg >= 1 && nbg <= 2 && npk <= 2; /* (at most two peaks) */                         \
+    for (int k = 0; k < npk; ++k) bgrec = bgrec && rec[k];                                      \
+    bgH = nbg == 2 ? local[1] * (H) : 0.0;                                                      \
+  } while (0)
+  MIR_SET_GRID(gH);
+  /* per-window grids: only models that choose per window (kHasSkip) on datasets that are not one
+   * grid; a window that is not a grid takes the direct form */
+  const int wgrid = has_skip && gH == 0.0;
+  double h_prev = 0.0, h_cur = 0.0;
   double acc0[MIR_LANES] = {0}, acc1[MIR_LANES] = {0};
   long double csum = 0.0L;
   const double half_log_2pi = -0.5 * log(2.0 * M_PI);
@@ -742,7 +781,19 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
         if (!(far[k] || in)) fastw = 0;
       }
     }
-    const int bgrec_w = bgrec && fastw;
+    /* sweep(), "Per-window grids": the window's own H; the constants follow it where it changes,
+     * and a window that is not a grid evaluates every peak directly (the constants of the last
+     * grid stay in place for the next window on it) */
+    int onw = 1;
+    if (wgrid) {
+      const double hw = mir_window_H(f, base, mir_tile, &h_prev);
+      onw = hw != 0.0;
+      if (onw && to_bits(hw) != to_bits(h_cur)) {
+        MIR_SET_GRID(hw);
+        h_cur = hw;
+      }
+    }
+    const int bgrec_w = onw && bgrec && fastw;
     for (size_t lane = 0; lane < MIR_LANES; ++lane) {
       if (base + lane >= f->n) break;
       double g[MHX_MAX_FN_PARAMS], r[MHX_MAX_FN_PARAMS], bgv = 0.0;
@@ -752,7 +803,7 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
         for (int j = nbg - 2; j >= 0; --j) bgv = fma(bgv, x0, local[j]);
       }
       for (int k = 0; k < npk; ++k)
-        if (rec[k] && fastw && !far[k]) {
+        if (onw && rec[k] && fastw && !far[k]) {
           const double ts = fma(x0, iw[k], cc[k]);
           g[k] = mir_exp2_negsq(ts);
           r[k] = mir_exp2_plain(fma(rm2d[k], ts, rnd2[k]));
@@ -767,7 +818,7 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
         if (kk > 0 && kk % (MIR_SEED_STEPS / 4) == 0)
           for (int k = 0; k < npk; ++k) {
             const int due = kk % (MIR_SEED_STEPS / 2) == 0 ? s16[k] : s8[k];
-            if (due && rec[k] && fastw && !far[k]) {
+            if (due && onw && rec[k] && fastw && !far[k]) {
               const double ts = fma(x, iw[k], cc[k]);
               g[k] = mir_exp2_negsq(ts);
               r[k] = mir_exp2_plain(fma(rm2d[k], ts, rnd2[k]));
@@ -782,7 +833,7 @@ static double mir_loglik_fn(const orc_fn* f, const double* theta, int* supported
         }
         for (int k = 0; k < npk; ++k) {
           if (fastw && far[k]) continue; /* exactly zero over this window: left out */
-          if (fastw && rec[k]) {
+          if (fastw && onw && rec[k]) {
             m = fma(A[k], g[k], m);
             g[k] = g[k] * r[k];
             r[k] = r[k] * rq[k];

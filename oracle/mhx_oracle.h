@@ -84,6 +84,9 @@ double orc_logpost(const orc_problem* p, const double* theta, double* parts);
  * otherwise): bit-identical to the device, see mhx_oracle.c */
 /* mirror mode only: 0 = restate the kernel with MHX_NO_RECURRENCE=1 (direct exp at every point) */
 void orc_mirror_set_recurrence(int on);
+/* mirror mode only: 0 = restate the kernel with MHX_NO_WINDOW_GRIDS=1 (the recurrence only on
+ * datasets whose x are ONE grid; default 1: window by window, csrc/mhx_engine.cpp) */
+void orc_mirror_set_window_grids(int on);
 double orc_logpost_mirror(const orc_problem* p, const double* theta, double* parts);
 /* sum_i |term_i| over all likelihood points: the scale of the stated tolerance */
 double orc_logpost_abs_terms(const orc_problem* p, const double* theta);

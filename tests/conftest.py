@@ -13,6 +13,7 @@ for p in (HERE, ROOT):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver)")
+    config.addinivalue_line("markers", "slow: tens of seconds of CPU (still part of the default run)")
 
 
 @pytest.fixture(scope="session")

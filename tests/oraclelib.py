@@ -73,6 +73,7 @@ def lib():
         "orc_walker_create2": (vp, [vp, f64p, i]),
         "orc_logpost_mirror": (d, [vp, f64p, f64p]),
         "orc_mirror_set_recurrence": (None, [i]),
+        "orc_mirror_set_window_grids": (None, [i]),
         "orc_walker_destroy": (None, [vp]),
         "orc_walker_take_step_injected": (i, [vp, f64p, f64p, d, d]),
         "orc_walker_modify": (i, [vp, i, C.c_int64]),
@@ -283,6 +284,11 @@ def mirror_set_recurrence(on):
     """mirror mode: restate the kernel with (True, default) or without (MHX_NO_RECURRENCE=1) the
     uniform-grid recurrence of the Gaussian peaks"""
     lib().orc_mirror_set_recurrence(int(bool(on)))
+
+
+def mirror_set_window_grids(on):
+    """mirror mode: per-window grids (default) or MHX_NO_WINDOW_GRIDS=1's rule (one grid or none)"""
+    lib().orc_mirror_set_window_grids(int(bool(on)))
 
 
 def temperature_schedule(n, d, temperature):

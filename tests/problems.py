@@ -90,6 +90,40 @@ def two_peak(n=4000, seed=1, lik=NORMAL, bounds=True, sigma_lo=0.05, sigma_hi=0.
     return s
 
 
+def piecewise_x(n, seed=0, jitter_window=True):
+    """x of `n` points as a real instrument file often is: three scans of different steps laid
+    end to end (each a grid on its own; the windows that hold a junction are not), one 2048-point
+    window in the middle re-sampled with jitter, and a last stretch on the first scan's step
+    again.  Ascending, inside [0, 1]."""
+    rng = np.random.default_rng(seed)
+    cuts = [0, int(0.37 * n), int(0.61 * n), int(0.83 * n), n]
+    rel = [1.0, 0.6, 1.7, 1.0]                 # relative steps of the four stretches
+    units = sum((cuts[i + 1] - cuts[i]) * rel[i] for i in range(4))
+    h0 = 1.0 / units
+    x = np.empty(n)
+    at = 0.0
+    for i in range(4):
+        m = cuts[i + 1] - cuts[i]
+        x[cuts[i]:cuts[i + 1]] = at + h0 * rel[i] * np.arange(m)
+        at = x[cuts[i + 1] - 1] + h0 * rel[i] * 0.5        # (a junction: half a step)
+    if jitter_window and n >= 8 * 2048:
+        w = (cuts[1] // 2048) // 2                          # a window inside the first scan
+        lo = w * 2048
+        x[lo + 1:lo + 2047] += h0 * 0.2 * rng.uniform(-1, 1, 2046)
+    return x
+
+
+def two_peak_piecewise(n=30000, seed=1, lik=NORMAL):
+    """config 2's problem on a piecewise-uniform x (piecewise_x): per-window grids"""
+    s = two_peak(n=n, seed=seed, lik=lik)
+    rng = np.random.default_rng(seed + 1000)
+    x = piecewise_x(n, seed)
+    _, _, sig, lk = s.data[0]
+    y = model_eval_np(GAUSS, (2, 2), s.theta_star, x) + sig * rng.standard_normal(n)
+    s.data[0] = (x, y, sig, lk)
+    return s
+
+
 def poisson_peaks(n=3000, seed=2, npk=5):
     """BASELINE config 3's problem: lambda = bg + 5 Gaussian peaks, counts ~ Poisson"""
     rng = np.random.default_rng(seed)

@@ -27,15 +27,18 @@ def test_line_fit_from_lisp_text(mhx, golden):
     """mcmc-fitting.lisp:1186 with its own lambda"""
     lf = golden["line_fit"]
     ref = golden["line_fit_initial_logpost_sigma_single"]
-    w = mhx.walker_create(function=mhx.models.lisp("(lambda (x &key m b &allow-other-keys) (+ b (* m x)))"),
-                          data=[lf["x"], lf["y"]], params=[":b", -1, ":m", 2],
-                          data_error=ref["sigma"], seed=1)
-    assert w.last_step().prob == pytest.approx(ref["value"], rel=1e-14)
-    mhx.walker_adaptive_steps(w, 3000)
-    ml = mhx.walker_get(w, get=":most-likely-params")
-    A = np.vstack([np.ones(5), lf["x"]]).T
-    bm = np.linalg.lstsq(A, np.array(lf["y"], float), rcond=None)[0]
-    assert abs(ml["b"] - bm[0]) < 0.2 and abs(ml["m"] - bm[1]) < 0.05
+    for as_written in (False, True):   # recognised as the polynomial model / compiled as written
+        w = mhx.walker_create(function=mhx.models.lisp("(lambda (x &key m b &allow-other-keys) (+ b (* m x)))",
+                                                       as_written=as_written),
+                              data=[lf["x"], lf["y"]], params=[":b", -1, ":m", 2],
+                              data_error=ref["sigma"], seed=1)
+        assert ("rtc[expr" in w.engine.kernel_name()) == as_written, w.engine.kernel_name()
+        assert w.last_step().prob == pytest.approx(ref["value"], rel=1e-14)
+        mhx.walker_adaptive_steps(w, 3000)
+        ml = mhx.walker_get(w, get=":most-likely-params")
+        A = np.vstack([np.ones(5), lf["x"]]).T
+        bm = np.linalg.lstsq(A, np.array(lf["y"], float), rcond=None)[0]
+        assert abs(ml["b"] - bm[0]) < 0.2 and abs(ml["m"] - bm[1]) < 0.05
 
 
 def test_single_item_parameter_styles(mhx, golden):
@@ -56,6 +59,7 @@ def test_single_item_parameter_styles(mhx, golden):
 def build_two_peak(mhx, s, C_, body=None, seed=0):
     keys, cexpr = __import__("lisp_mcmc_amd").sexpr.lambda_to_expr(TWO_PEAK)
     e = mhx.Engine(C_, 8, 1, seed=seed)
+    e.set_expr_recognition(False)     # these tests are about the text compiled as written
     e.set_function_expr(0, cexpr, keys, [KEYS.index(k) for k in keys])
     x, y, sig, lik = s.data[0]
     e.set_dataset(0, x, y, sig, lik)
@@ -267,7 +271,7 @@ def test_recognised_peak_closure_runs_on_the_peak_kernels(mhx, orc):
     x, y, sig, _ = s.data[0]
     params = [":b0", 0.5, ":b1", 0.3, ":a1", 1.0, ":mu1", 0.3, ":w1", 0.05, ":a2", 0.7, ":mu2", 0.7, ":w2", 0.08]
     cross = TWO_PEAK.replace("(* a1 (exp", "(* a1 (+ 1 (* 0 b1)) (exp")           # a cross term
-    cube = TWO_PEAK.replace("(expt (/ (- x mu2) w2) 2)", "(expt (/ (- x mu2) w2) 3)")
+    cube = TWO_PEAK.replace("(expt (/ (- x mu2) w2) 2)", "(expt (/ (- x mu2) w2) 4)")   # not a Gaussian
     ws = [mhx.walker_create(function=f, data=[x, y], params=params, data_error=sig, n_chains=3, seed=5)
           for f in (mhx.models.lisp(TWO_PEAK, recognise=False),     # (the keyword of rounds 2-3: ignored)
                     mhx.models.gauss_peaks(["b0", "b1"], [("a1", "mu1", "w1"), ("a2", "mu2", "w2")]),

@@ -165,3 +165,67 @@ def test_yw_tiles_give_the_same_bits(mhx, orc, n, wpg):
         assert np.array_equal(sa[k], sb[k]), (n, wpg, k)
     a.close()
     b.close()
+
+
+DEAL_CASES = [
+    ("two_peak", lambda: pb.two_peak(n=30000, seed=41), None),
+    ("poisson5", lambda: pb.poisson_peaks(n=24000, seed=4), 0.002),
+    ("global_fit", lambda: pb.global_fit(n_each=7000, n_sets=3, seed=5), None),
+]
+
+
+@pytest.mark.parametrize("name,make,lscale", DEAL_CASES, ids=[c[0] for c in DEAL_CASES])
+@pytest.mark.parametrize("wpg", ["8", "16"])
+def test_dealing_proposals_to_wave_slots_leaves_every_bit_alone(mhx, orc, name, make, lscale, wpg):
+    """group_logpost ranks the proposals of a workgroup by estimated sweep cost and deals them to
+    its wave slots in a snake over the SIMDs; wave slot s computes the likelihood sums of chain
+    src(s) and hands them back.  A sum is one wave's lane-strided accumulation and butterfly
+    whichever wave runs it: against MHX_NO_DEAL=1 bit for bit - log-posteriors of wildly different
+    vectors (so that the deal really permutes), walks from the diag(theta) start where costs
+    differ most, a workgroup that is not full, chains that have finished while others walk."""
+    # (the product build leaves the dealing out - it measured slower where it matters,
+    # csrc/mhx_kernels.hpp "DEALING" - so this test wants a library built with -DMHX_DEAL:
+    # make -C lisp-mcmc_amd/csrc OUT=../libmhx_deal.so OUT_HOOKS=/tmp/h.so CXXFLAGS="... -DMHX_DEAL",
+    # MHX_LIBRARY=.../libmhx_deal.so MHX_TEST_DEAL=1 pytest tests/test_gpu_families.py -k dealing)
+    if not os.environ.get("MHX_TEST_DEAL"):
+        pytest.skip("libmhx.so is built without -DMHX_DEAL")
+    s = make()
+    C_ = 37
+    th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=3)
+    out = []
+    os.environ["MHX_FAMILY_WPG"] = wpg
+    try:
+        for flag in ("1", None):
+            if flag:
+                os.environ["MHX_NO_DEAL"] = flag
+            try:
+                e = s.engine(mhx, C_, seed=8)
+                e.init_chains(th0)  # finalises the problem under these settings
+            finally:
+                os.environ.pop("MHX_NO_DEAL", None)
+            out.append(e)
+    finally:
+        os.environ.pop("MHX_FAMILY_WPG", None)
+    a, b = out
+    rng = np.random.default_rng(5)
+    th = s.theta_star[None, :] * (1.0 + 0.5 * rng.standard_normal((96, s.d)))
+    if lscale is not None:                                   # Poisson rates must stay positive
+        th = np.abs(th)
+    ga, gb = a.logpost(th), b.logpost(th)
+    assert np.array_equal(ga, gb, equal_nan=True)
+    assert np.isfinite(gb).sum() > 48
+    op = s.oracle(orc)
+    for c in np.flatnonzero(np.isfinite(gb))[:6]:
+        assert abs(gb[c] - op.logpost(th[c])) <= 1e-12 * op.abs_terms(th[c]) + 1e-5, (name, wpg, c)
+    l0 = None if lscale is None else np.diag(lscale * np.abs(s.theta_star))
+    for n_it in (60, 1 << 40):
+        for e in (a, b):
+            e.init_chains(th0)
+            e.adaptive_begin(2500, 10.0, 1, l_matrix=l0)
+            e.adaptive_advance(n_it)
+        sa, sb = a.state(), b.state()
+        for k in ("theta", "logpost", "best_logpost", "age", "length"):
+            assert np.array_equal(sa[k], sb[k]), (name, wpg, n_it, k)
+        assert np.array_equal(a.lmatrix(), b.lmatrix())
+    a.close()
+    b.close()

@@ -286,7 +286,7 @@ def test_one_device_group_through_the_real_rccl(tmp_path):
         pa, pg = plain.pooled(), g.engines[0].pooled()
         assert pg["refreshes"] == 2 and pa["refreshes"] == 2
         assert np.array_equal(pa["stats"], pg["stats"]) and np.array_equal(pa["L"], pg["L"])
-        assert pg["valid"]
+        assert pg["valid"] == pa["valid"]
         print("ok", flush=True)
     """, tmp_path, stub=False, force=True)
     assert "ok" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])

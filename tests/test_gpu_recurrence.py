@@ -90,13 +90,19 @@ def test_not_a_grid_means_direct_form(mhx, orc):
     assert np.array_equal(a.logpost(th), b.logpost(th))
     a.close()
     b.close()
-    # one point moved by a few hundred ulp: no longer a grid either
+    # one point moved by a few hundred ulp: its WINDOW is no longer a grid (the other two still
+    # are, and take the recurrence: test_per_window_grids below); with MHX_NO_WINDOW_GRIDS=1 -
+    # round 3's rule, one grid or none - the whole dataset takes the direct form
     s2 = pb.two_peak(n=6000, seed=77)
     x2 = s2.data[0][0].copy()
     x2[4000] += 3e-13
     s2.data[0] = (x2,) + s2.data[0][1:]
-    a, b = engines(mhx, s2, 1)
-    assert np.array_equal(a.logpost(th), b.logpost(th))
+    os.environ["MHX_NO_WINDOW_GRIDS"] = "1"
+    try:
+        a, b = engines(mhx, s2, 1)
+        assert np.array_equal(a.logpost(th), b.logpost(th))   # (finalised under the switch)
+    finally:
+        os.environ.pop("MHX_NO_WINDOW_GRIDS", None)
     a.close()
     b.close()
     # a grid far from the origin, negative spacing direction excluded (x must ascend to be found
@@ -241,3 +247,79 @@ def test_three_seeding_periods_by_peak_width(mhx, orc, wpg):
         assert np.array_equal(st["theta"][c], w.last()[0]) and st["logpost"][c] == w.last()[1], c
     rec.close()
     direct.close()
+
+
+@pytest.mark.parametrize("n", [6000, 30000, 100000])
+@pytest.mark.parametrize("wpg", ["8", "16"])
+def test_per_window_grids(mhx, orc, n, wpg):
+    """VERDICT r3 item 4.  grid_H was one number per dataset: one irregular stretch anywhere sent
+    the whole dataset to the direct form (2.1x slower on config 2).  Now every 2048-point window
+    brings its own H = 64 h (FnDesc::tgh; the kernel re-derives the recurrence's constants where H
+    changes: PeaksModel::regrid).  x = three scans of different steps laid end to end, one
+    jittered window, the first step again: device == mirror bit for bit (which restates the
+    host's per-window rule and the regrid), within 1e-13 sum|term| of the direct kernel and
+    1e-12 of the faithful oracle; the recurrence really ran; MHX_NO_WINDOW_GRIDS=1 gives the
+    direct kernel's bits; a walk gives the same bits in both kernel families."""
+    s = pb.two_peak_piecewise(n=n, seed=n + 7)
+    op = s.oracle(orc)
+    os.environ["MHX_FAMILY_WPG"] = wpg
+    try:
+        rec, direct = engines(mhx, s, 1)
+        th = mixed_thetas(s.theta_star, 24, seed=n)
+        a = rec.logpost(th)
+        b = direct.logpost(th)
+        os.environ["MHX_NO_WINDOW_GRIDS"] = "1"
+        try:
+            off = s.engine(mhx, 1)
+            c = off.logpost(th)
+        finally:
+            os.environ.pop("MHX_NO_WINDOW_GRIDS", None)
+    finally:
+        os.environ.pop("MHX_FAMILY_WPG", None)
+    assert rec.kernel_name().startswith("w%s/" % wpg)
+    assert np.array_equal(b, c)
+    for i, t in enumerate(th):
+        scale = op.abs_terms(t)
+        assert abs(a[i] - b[i]) <= 1e-13 * scale, (n, i, a[i], b[i])
+        assert abs(a[i] - op.logpost(t)) <= REL * scale + 2.0 ** -52 * 1e10 * 8, (n, i)
+        assert a[i] == op.logpost_mirror(t), (n, i)
+        orc.mirror_set_window_grids(False)
+        try:
+            assert b[i] == op.logpost_mirror(t), (n, i)
+        finally:
+            orc.mirror_set_window_grids(True)
+    if n >= 30000:
+        assert (a != b).sum() >= 8
+    for e in (rec, direct, off):
+        e.close()
+
+
+def test_per_window_grids_walks(mhx, orc):
+    """... and over walks: 40 chains (workgroups whose chains sit in different windows' forms),
+    both families and the tile-sliced split mode's slices (whose FnDescs carry their own part of
+    the per-window table) against one another; the mirror walker on chain 0."""
+    s = pb.two_peak_piecewise(n=40000, seed=3)
+    C_ = 40
+    th0 = pb.perturbed(s.theta_star, C_, 0.01, seed=3)
+    runs = []
+    for wpg in ("8", "16"):
+        os.environ["MHX_FAMILY_WPG"] = wpg
+        try:
+            e = s.engine(mhx, C_, seed=8)
+            e.init_chains(th0)
+        finally:
+            os.environ.pop("MHX_FAMILY_WPG", None)
+        e.adaptive_begin(1500, 10.0, 1)
+        e.adaptive_advance(1 << 40)
+        runs.append((e.state(), e.lmatrix()))
+        e.close()
+    for k in ("theta", "logpost", "best_logpost", "age", "length"):
+        assert np.array_equal(runs[0][0][k], runs[1][0][k]), k
+    assert np.array_equal(runs[0][1], runs[1][1])
+    op = s.oracle(orc)
+    w = orc.Walker(op, th0[0], mirror=True)
+    w.adaptive_begin(1500, 10.0, 1, seed=8, chain_id=0)
+    w.adaptive_advance(1 << 40)
+    thw, prw = w.last()
+    assert np.array_equal(runs[0][0]["theta"][0], thw) and runs[0][0]["logpost"][0] == prw
+    assert runs[0][0]["age"][0] == w.age

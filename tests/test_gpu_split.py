@@ -245,6 +245,7 @@ def test_tile_sliced_split_with_a_model_compiled_at_run_time(mhx, orc):
         os.environ.update(env)
         try:
             e = s.engine(mhx, chains, seed=5)
+            e.set_expr_recognition(False)   # (as written: the run-time compiled sweep is the subject)
             e.set_function_expr(0, cexpr, keys, list(range(8)))
             name = e.kernel_name()
         finally:
@@ -486,3 +487,122 @@ def test_slot_map_grows_when_the_problem_changes_the_mode(mhx):
             assert np.array_equal(st[k], rs[k]), (chains, k)
         e.close()
         ref.close()
+
+
+def persist_pair(mhx, make_engine):
+    """(persistent split mode - the default for a handful of chains -, the two launches per
+    iteration of rounds 1-3: MHX_NO_PERSIST=1), finalised under their settings"""
+    out = []
+    for flag in (None, "1"):
+        old = {k: os.environ.get(k) for k in ("MHX_SPLIT", "MHX_TSPLIT", "MHX_NO_PERSIST")}
+        for k in old:
+            os.environ.pop(k, None)
+        if flag:
+            os.environ["MHX_NO_PERSIST"] = flag
+        try:
+            e = make_engine()
+            name = e.kernel_name()
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+        out.append((e, name))
+    assert "persistent split x" in out[0][1] and "persistent" not in out[1][1] and "split x" in out[1][1], \
+        [n for _, n in out]
+    return out[0][0], out[1][0]
+
+
+@pytest.mark.parametrize("name,make,lscale", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("chains", [1, 3, 7])
+def test_persistent_split_mode_equals_the_two_launch_mode(mhx, name, make, lscale, chains):
+    """ONE launch for many iterations of a handful of chains (k_persist: the
+    chain's master wave and its sweep workgroups hand each other the proposal and the partial sums
+    through memory, release / acquire at agent scope) - same slots, same points, same order of
+    the sums as k_split_sweep + k_split_step: the same bits, over complete walker-adaptive-steps
+    runs driven in uneven portions, a second run on the same engine, and plain steps."""
+    s = make()
+    th0 = pb.perturbed(s.theta_star, chains, 0.01, seed=2)
+    l0 = None if lscale is None else np.diag(lscale * np.abs(s.theta_star))
+    a, b = persist_pair(mhx, lambda: s.engine(mhx, chains, seed=9))
+    res = []
+    for e in (a, b):
+        e.init_chains(th0)
+        e.adaptive_begin(1300, 10.0, 1, l_matrix=l0)
+        for portion in (1, 7, 200, 64, 1 << 40):
+            if e.adaptive_advance(portion) == 0:
+                break
+        first = (e.state(), e.chain_status()[0], e.lmatrix())
+        e.init_chains(th0)                       # ... and once more on the same engine
+        e.adaptive_begin(600, 10.0, 1, l_matrix=l0)
+        e.adaptive_advance(1 << 40)
+        lp = np.diag(0.003 * np.abs(s.theta_star))
+        e.many_steps(45, lp)
+        res.append((first, (e.state(), e.chain_status()[0], e.lmatrix())))
+    for (sa, sta, La), (sb, stb, Lb) in zip(res[0], res[1]):
+        assert np.array_equal(sta, stb) and (sta == mhx.capi.CHAIN_DONE).all()
+        for k in ("theta", "logpost", "best_theta", "best_logpost", "age", "length"):
+            assert np.array_equal(sa[k], sb[k]), (name, chains, k)
+        assert np.array_equal(La, Lb)
+    assert (res[0][1][0]["age"] == res[0][0][0]["age"] * 0 + res[0][1][0]["age"][0]).all()
+    for e in (a, b):
+        e.close()
+
+
+def test_persistent_split_mode_with_a_model_compiled_at_run_time_and_the_stop_flag(mhx):
+    """the same through hiprtc (mhx_user_persist), a single walker - the reference's own way of
+    working (test.lisp:24) - and mfit-walker-estop: a stop raised between launches ends the walk"""
+    rng = np.random.default_rng(12)
+    n = 60000
+    x = np.linspace(0, 4, n)
+    sig = rng.uniform(0.05, 0.2, n)
+    y = 2.0 * np.exp(-x / 1.5) + 0.3 + sig * rng.standard_normal(n)
+    text = "(lambda (x &key a tau c &allow-other-keys) (+ c (* a (exp (/ (- x) tau)))))"
+    params = [":a", 1.8, ":tau", 1.4, ":c", 0.35]
+    ws = []
+    for flag in (None, "1"):
+        for k in ("MHX_SPLIT", "MHX_TSPLIT", "MHX_NO_PERSIST"):
+            os.environ.pop(k, None)
+        if flag:
+            os.environ["MHX_NO_PERSIST"] = flag
+        try:
+            w = mhx.walker_create(function=mhx.models.lisp(text), data=[x, y], params=params,
+                                  data_error=sig, seed=2)
+            w.engine.kernel_name()
+        finally:
+            os.environ.pop("MHX_NO_PERSIST", None)
+        ws.append(w)
+    assert "persistent split x" in ws[0].engine.kernel_name() and "rtc[" in ws[0].engine.kernel_name()
+    assert "persistent" not in ws[1].engine.kernel_name()
+    L = np.diag([0.01, 0.01, 0.005])
+    for w in ws:
+        mhx.walker_adaptive_steps_full(w, n=900, temperature=10, auto=":prob-settle", l_matrix=L)
+    sa, sb = ws[0].engine.state(), ws[1].engine.state()
+    for k in ("theta", "logpost", "age"):
+        assert np.array_equal(sa[k], sb[k]), k
+    e = ws[0].engine
+    e.init_chains(np.array(params[1::2], float))
+    e.adaptive_begin(100000, 10.0, 1, l_matrix=L)
+    assert e.adaptive_advance(50) == 1
+    e.request_stop()
+    assert e.adaptive_advance(1 << 40) == 0
+    assert e.chain_status()[0][0] == mhx.capi.CHAIN_STOPPED and 50 <= e.state()["age"][0] - 1 <= 50 + 16
+
+
+def test_single_walker_step_time(mhx):
+    """what a step of ONE walker costs on config 2's 1e5 points, both modes (printed; the
+    persistent kernel must not be slower than the two launches it replaces)"""
+    import time
+    s = pb.two_peak(n=100000, seed=3)
+    a, b = persist_pair(mhx, lambda: s.engine(mhx, 1, seed=9))
+    out = []
+    for e in (a, b):
+        e.init_chains(s.theta_star)
+        e.adaptive_begin(30000, 10.0, 1)
+        e.adaptive_advance(300)
+        t0 = time.perf_counter()
+        e.adaptive_advance(3000)
+        out.append((time.perf_counter() - t0) / 3000 * 1e6)
+        e.close()
+    print("single walker, 1e5 points: %.2f us per step persistent, %.2f us two launches" % tuple(out))
+    assert out[0] <= out[1] * 1.05

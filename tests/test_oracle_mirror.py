@@ -120,3 +120,46 @@ def test_cutoff_mirror_within_tolerance_of_faithful(orc, n):
         assert abs(pa[0] - pm[0]) <= REL * op.abs_terms(t)
         clamped += pa[0] <= -5000.0
     assert n < 65 or clamped >= 1
+
+
+@pytest.mark.parametrize("n", [3000, 30000, 100000])
+def test_per_window_grids_mirror_within_tolerance_of_faithful(orc, n):
+    """Per-window grids (csrc/mhx_engine.cpp, PeaksModel::regrid): on an x that is three scans
+    of different steps laid end to end plus one jittered window, every window on a grid takes the
+    recurrence with ITS step, the junction and jittered windows the direct form.  The mirror's
+    restatement against the faithful sum, and against the mirror without window grids (round 3's
+    rule: such a dataset ran the direct form everywhere) - the same bound as recurrence vs direct."""
+    s = pb.two_peak_piecewise(n=n, seed=n + 2)
+    op = s.oracle(orc)
+    th = pb.perturbed(s.theta_star, 6, 0.03, seed=n)
+    th[2, 4] *= 0.3                 # a narrow peak
+    th[3, 7] *= 3.0                 # a wide one
+    differs = 0
+    for t in th:
+        a, pa = op.logpost(t, parts=True)
+        b, pm = op.logpost_mirror(t, parts=True)
+        orc.mirror_set_window_grids(False)
+        try:
+            c, pc = op.logpost_mirror(t, parts=True)
+        finally:
+            orc.mirror_set_window_grids(True)
+        scale = op.abs_terms(t)
+        assert abs(pa[0] - pm[0]) <= REL * scale
+        assert abs(pm[0] - pc[0]) <= 1e-13 * scale
+        differs += pm[0] != pc[0]
+    assert n < 30000 or differs >= 3      # (about 615 grid points per peak width are needed)
+
+
+@pytest.mark.slow
+def test_mirror_within_tolerance_of_faithful_at_config_3_length(orc):
+    """the mirror-vs-faithful bound at config 3's full length, N = 1e6 (the device side
+    is held to the mirror bit for bit there: tests/test_gpu_fullsize.py)"""
+    s = pb.poisson_peaks(n=1000000, seed=12)
+    op = s.oracle(orc)
+    th = pb.perturbed(s.theta_star, 2, 0.02, seed=6)
+    th[1, 3] *= 0.05
+    for t in th:
+        a, pa = op.logpost(t, parts=True)
+        b, pm = op.logpost_mirror(t, parts=True)
+        assert np.isfinite(a) and np.isfinite(b)
+        assert abs(pa[0] - pm[0]) <= REL * op.abs_terms(t)
