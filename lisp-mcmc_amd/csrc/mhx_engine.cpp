@@ -467,6 +467,15 @@ const Family& choose_family(const mhx_engine* e) {
   return big ? family_w16() : family_w8();
 }
 
+// workgroups of the stepping kernels the GPU holds at once, with a tenth in hand: what a
+// persistent launch (k_persist, k_persist_ts) may ask for - its workgroups wait for one another
+int64_t persist_capacity(const mhx_engine* e) {
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus <= 0)
+    cus = 256;
+  return (int64_t)cus * (e->fam->waves_per_group <= 8 ? 2 : 1) * 9 / 10;
+}
+
 int finalize_problem(mhx_engine* e) {
   if (!e->problem_dirty) return MHX_OK;
   drop_split_graph(e);
@@ -714,17 +723,40 @@ int finalize_problem(mhx_engine* e) {
     // through memory, which needs every workgroup of the launch on the GPU at once
     // (MHX_NO_PERSIST=1: the two launches per iteration of rounds 1-3)
     e->persist = false;
-    if (e->split_slices > 0 && !e->tsplit) {
+    if (e->split_slices > 0) {
       const char* np_ = getenv("MHX_NO_PERSIST");
-      int cus = 0;
-      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus <= 0)
-        cus = 256;
-      const int64_t resident = (int64_t)cus * (e->fam->waves_per_group <= 8 ? 2 : 1);
-      const int64_t groups = e->cfg.n_chains * (1 + (int64_t)e->split_slices);
-      e->persist = !(np_ && atoi(np_) != 0) && groups * 10 <= resident * 9 && e->P.d <= 60;
+      const int64_t W = e->fam->waves_per_group;
+      // tile-sliced: (1 + slices) workgroups per chain GROUP - with fewer slices, down to 2,
+      // where the default slicing would not fit the GPU at once (a run's repacking keeps to the
+      // same bound: compact_tsplit)
+      const int64_t units = e->tsplit ? (e->cfg.n_chains + W - 1) / W : e->cfg.n_chains;
+      const int64_t cap = persist_capacity(e);
+      int64_t slices = e->split_slices;
+      if (e->tsplit && getenv("MHX_PERSIST_TS") && atoi(getenv("MHX_PERSIST_TS")) != 0 && !getenv("MHX_TSPLIT"))
+        slices = std::min<int64_t>(slices, cap / units - 1);
+      // (the tile-sliced form is built and bit-identical, but no faster than its two launches -
+      // 64 walkers on 1e5 points 20.5 against 19.9 us per iteration, 256: 31.8 against 31.2, and
+      // slower where the GPU does not hold the default slicing at once (1024: 103 against 69) -
+      // so it waits behind MHX_PERSIST_TS=1; the per-chain form halves a single walker's step)
+      const char* pts = getenv("MHX_PERSIST_TS");
+      const bool want = e->tsplit ? (pts && atoi(pts) != 0) : true;
+      e->persist = want && !(np_ && atoi(np_) != 0) && slices >= (e->tsplit ? 2 : 1) &&
+                   units * (1 + slices) <= cap && e->P.d <= 60;
+      if (e->persist && e->tsplit && slices != e->split_slices) {
+        const int rc = build_ts_table(e, (int)slices);
+        if (rc != MHX_OK) return rc;
+        e->split_slices = (int)slices;
+        e->S.split_slots = (int)slices;
+        e->ts_initial = (int)slices;
+      }
       if (e->persist) {
         const size_t nm = 64 * (size_t)e->cfg.n_chains;
-        const size_t npb = 16 * (size_t)e->cfg.n_chains * e->P.K * (size_t)e->S.split_slots;
+        int64_t nwin_all = 1;
+        for (int k = 0; k < e->P.K; ++k)
+          nwin_all = std::max<int64_t>(nwin_all, (e->P.fn[k].n + kPadPoints - 1) / kPadPoints);
+        const size_t slots_cap = e->tsplit ? (size_t)std::max<int64_t>(e->S.split_slots, std::min<int64_t>(nwin_all, 512))
+                                           : (size_t)e->S.split_slots;
+        const size_t npb = 16 * (size_t)e->cfg.n_chains * e->P.K * slots_cap;
         if ((e->persist_msg.n < nm && e->persist_msg.alloc(nm) != hipSuccess) ||
             (e->persist_part.n < npb && e->persist_part.alloc(npb) != hipSuccess))
           return fail(MHX_ENOMEM, "hipMalloc of the persistent kernel's handshake buffers failed");
@@ -751,7 +783,8 @@ int finalize_problem(mhx_engine* e) {
     if (!e->rtc_note.empty()) e->kernel_name += " [not specialised: " + e->rtc_note + "]";
   }
   if (e->split_slices > 0)
-    e->kernel_name += (e->tsplit ? " tsplit x" : (e->persist ? " persistent split x" : " split x")) +
+    e->kernel_name += (e->tsplit ? (e->persist ? " persistent tsplit x" : " tsplit x")
+                                 : (e->persist ? " persistent split x" : " split x")) +
                       std::to_string(e->split_slices);
   e->problem_dirty = false;
   return MHX_OK;
@@ -790,6 +823,12 @@ hipError_t do_split_step(mhx_engine* e, int mode, int plain) {
              : e->fam->split_step(e->spec, e->stream, e->dP.p, e->S, e->R, mode, plain);
 }
 hipError_t do_persist(mhx_engine* e, int64_t iters, int plain) {
+  if (e->tsplit)
+    return e->spec == SPEC_USER
+               ? rtc_launch_persist_ts(*e->user_prog, e->stream, e->dP.p, e->ts_table.p, e->S, e->R,
+                                       e->split_slices, iters, plain)
+               : e->fam->persist_ts(e->spec, e->stream, e->dP.p, e->ts_table.p, e->S, e->R,
+                                    e->split_slices, iters, plain);
   return e->spec == SPEC_USER
              ? rtc_launch_persist(*e->user_prog, e->stream, e->dP.p, e->S, e->R, e->split_slices, iters, plain)
              : e->fam->persist(e->spec, e->stream, e->dP.p, e->S, e->R, e->split_slices, iters, plain);
@@ -985,9 +1024,11 @@ int compact_tsplit(mhx_engine* e, const std::vector<int32_t>& st, int64_t runnin
   for (int k = 0; k < e->P.K; ++k)
     nwin = std::max<int64_t>(nwin, (e->P.fn[k].n + kPadPoints - 1) / kPadPoints);
   const char* forced = getenv("MHX_TSPLIT");
-  const int64_t ts = forced ? e->split_slices
-                            : std::max<int64_t>(e->split_slices,
-                                                std::min<int64_t>(std::min<int64_t>(512 / groups, nwin), 512));
+  int64_t ts = forced ? e->split_slices
+                      : std::max<int64_t>(e->split_slices,
+                                          std::min<int64_t>(std::min<int64_t>(512 / groups, nwin), 512));
+  if (e->persist && !forced)  // (every workgroup of a persistent launch on the GPU at once)
+    ts = std::max<int64_t>(2, std::min<int64_t>(ts, persist_capacity(e) / groups - 1));
   if (ts != e->split_slices) {
     const int rc = build_ts_table(e, (int)ts);
     if (rc != MHX_OK) return rc;
@@ -1143,7 +1184,7 @@ int launch_steps_enqueue(mhx_engine* e, int64_t iters, int plain) {
     if (rc != MHX_OK) return rc;
   }
   HIP_TRY(hipEventRecord(e->ev0, e->stream));
-  if (e->split_slices > 0 && e->persist) {
+  if (e->split_slices > 0 && e->persist && !e->tsplit) {
     // persistent split mode: one launch, `iters` iterations (the kernel leaves its loop when no
     // chain is running any more); the sync words start every launch at zero
     // (launches of at most 2^22 iterations: what mhx_adaptive_advance asks for at most anyway)
@@ -1172,6 +1213,11 @@ int launch_steps_enqueue(mhx_engine* e, int64_t iters, int plain) {
     while (left > 0) {
       // (portions end where split_iter is a multiple of their length, whatever the caller asked for)
       const int64_t now = std::min<int64_t>(left, portion - e->split_iter % portion);
+      // (round 4 tried ONE launch per iteration - the last workgroup of a chain group, by an
+      // atomic ticket, running the group's step at the end of the sweep's launch: bit-identical,
+      // and 27.7 us per iteration of 64 walkers where these two launches take 25.1: between two
+      // nodes of a graph lie 0.3 us; what an iteration costs are the dependent memory round
+      // trips inside both kernels, which the fusion only lines up behind a ticket)
       auto issue = [&](int64_t count) -> hipError_t {
         hipError_t he = do_split_step(e, 0, plain);
         for (int64_t it = 0; it < count && he == hipSuccess; ++it) {
@@ -1182,8 +1228,14 @@ int launch_steps_enqueue(mhx_engine* e, int64_t iters, int plain) {
       };
       const char* ng = getenv("MHX_NO_GRAPH");
       // (only whole portions: a remainder of another length would mean capturing again)
-      const bool use_graph = !(ng && atoi(ng) != 0) && now == e->split_portion;
+      const bool use_graph = !(ng && atoi(ng) != 0) && now == e->split_portion && !e->persist;
       bool done = false;
+      if (e->persist) {  // tile-sliced, persistent: the portion is ONE launch (k_persist_ts)
+        HIP_TRY(hipMemsetAsync(e->persist_msg.p, 0, e->persist_msg.n * sizeof(unsigned long long), e->stream));
+        HIP_TRY(hipMemsetAsync(e->persist_part.p, 0, e->persist_part.n, e->stream));
+        HIP_TRY(do_persist(e, now, plain));
+        done = true;
+      }
       if (use_graph) {
         if (!e->split_graph || e->split_graph_iters != now || e->split_graph_plain != plain) {
           drop_split_graph(e);
@@ -1208,7 +1260,7 @@ int launch_steps_enqueue(mhx_engine* e, int64_t iters, int plain) {
         }
       }
       if (!done) HIP_TRY(issue(now));
-      e->launches += 2 * (uint64_t)now + 1;
+      e->launches += e->persist ? 1 : 2 * (uint64_t)now + 1;
       left -= now;
       e->split_iter += now;
       e->ts_repack_due = e->tsplit && e->split_iter % portion == 0;

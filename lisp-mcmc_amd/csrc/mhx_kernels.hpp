@@ -1196,13 +1196,21 @@ __device__ __forceinline__ double group_logpost(const ProblemDesc& P, bool activ
 // relaxed agent-scope atomics, and 16-byte loads / stores with the same cache policy), data and
 // tag in ONE naturally aligned unit - a 128-byte line of the proposal block, a 16-byte {sum,
 // generation} pair - so that who finds the tag finds the data, and nothing else leaves a cache.
-constexpr unsigned long long kPersistStop = 1ull << 62;  // tag: the chain's master is through
+// A tag word is {check << 32 | generation}: the low half the generation (or the stop bit), the
+// high half a 32-bit fold of the data the tag vouches for.  A reader that finds the generation it
+// waits for but another fold has caught the words of its line / pair in two states (a 128-byte
+// read is not promised to be atomic against a 128-byte write: seen once per ~1e6 polls) and
+// reads again.
+constexpr unsigned long long kPersistStop = 1ull << 31;  // generation half: the chain's master is through
+__device__ __forceinline__ unsigned persist_fold(unsigned long long v) {
+  return (unsigned)v ^ (unsigned)(v >> 32) ^ 0x9E3779B9u;
+}
 constexpr unsigned kPersistPatience = 1u << 20;   // polls (a memory round trip apart) before giving up
 constexpr int kPersistMaxParams = 60;             // four lines of 15 parameters and a tag
 typedef __attribute__((ext_vector_type(4))) unsigned int persist_u4;
-__device__ __forceinline__ void persist_store_pair(void* p, double v, unsigned long long tag) {
+__device__ __forceinline__ void persist_store_pair(void* p, double v, unsigned long long gen) {
   const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  const persist_u4 q = {(unsigned)b, (unsigned)(b >> 32), (unsigned)tag, (unsigned)(tag >> 32)};
+  const persist_u4 q = {(unsigned)b, (unsigned)(b >> 32), (unsigned)gen, persist_fold(b)};
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(q) : "memory");
 }
 __device__ __forceinline__ persist_u4 persist_load_pair(const void* p) {
@@ -1211,17 +1219,26 @@ __device__ __forceinline__ persist_u4 persist_load_pair(const void* p) {
                : "=v"(r) : "v"(p) : "memory");
   return r;
 }
-// the proposal (lane j < d: theta'_j) and its generation into the chain's block
+// the proposal (lane j < d: theta'_j) and its generation into the chain's block: ONE store
+// instruction of the wave, lanes 16 i .. 16 i + 15 writing line i - its 15 parameters and, from
+// lane 16 i + 15, its tag - as one 128-byte write.  (With the parameters first, a release fence,
+// then the tags, the fence's wait for the first stores' acknowledgement was a memory round trip
+// on the critical path of every iteration: 9.5 -> 9.2 us per step of a single walker.)
 __device__ __forceinline__ void persist_publish(const ChainState& S, int64_t c, int d, double thp,
                                                 unsigned long long gen) {
   unsigned long long* m = S.persist_msg + c * 64;
   const int l = lane_id();
-  if (l < d)
-    __hip_atomic_store(m + (l / 15) * 16 + l % 15, (unsigned long long)__double_as_longlong(thp),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the parameters first, then the tags
-  if ((l & 15) == 15)
-    __hip_atomic_store(m + l, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int e = (l >> 4) * 15 + (l & 15);  // the element this lane's word carries
+  const double v = __shfl(thp, e < kWave ? e : 0, kWave);
+  const unsigned long long data = ((l & 15) != 15 && e < d) ? (unsigned long long)__double_as_longlong(v) : 0ull;
+  unsigned f = (l & 15) != 15 ? persist_fold(data) : 0u;  // xor over the line's 15 data words
+  f ^= (unsigned)__shfl_xor((int)f, 1, kWave);
+  f ^= (unsigned)__shfl_xor((int)f, 2, kWave);
+  f ^= (unsigned)__shfl_xor((int)f, 4, kWave);
+  f ^= (unsigned)__shfl_xor((int)f, 8, kWave);
+  const unsigned long long word = (l & 15) == 15 ? (((unsigned long long)f << 32) | gen) : data;
+  if ((l >> 4) <= (d > 0 ? (d - 1) / 15 : 3))  // the lines in use (a stop word: all four)
+    __hip_atomic_store(m + l, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // split mode: the same value from the partial sums the sweep launch left in S.split_part
@@ -1251,8 +1268,9 @@ __device__ __forceinline__ double split_logpost(const ProblemDesc& P, const Chai
           bool have = true;
           if (sl < S.split_slots) {
             const persist_u4 q = persist_load_pair(pairs + (size_t)sl * 16);
-            have = (((unsigned long long)q.w << 32) | q.z) == gen;
-            v = __longlong_as_double((long long)(((unsigned long long)q.y << 32) | q.x));
+            const unsigned long long b = ((unsigned long long)q.y << 32) | q.x;
+            have = q.z == (unsigned)gen && q.w == persist_fold(b);
+            v = __longlong_as_double((long long)b);
           }
           if (__builtin_amdgcn_readfirstlane((int)(__ballot(!have) == 0ull))) break;
           if (++n >= kPersistPatience) {
@@ -1484,7 +1502,7 @@ __device__ __forceinline__ void k_step_injected_body(
 template <class Spec, bool SPLIT = false, bool PERSIST = false>
 __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ Pp, ChainState S,
                                                 RunDesc R, int64_t max_iters, int plain,
-                                                int mode = 1);
+                                                int mode = 1, int64_t group = -1);
 template <class Spec>
 __device__ __forceinline__ void k_split_sweep_body(const ProblemDesc* __restrict__ Pp,
                                                    ChainState S);
@@ -1775,7 +1793,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_adaptive(const ProblemDesc* __r
 template <class Spec, bool SPLIT, bool PERSIST>
 __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ Pp, ChainState S,
                                                 RunDesc R, int64_t max_iters, int plain,
-                                                int mode) {
+                                                int mode, int64_t group) {
   static_assert(SPLIT || !PERSIST, "the persistent kernel is a split-mode kernel");
   GroupLds& lds = *reinterpret_cast<GroupLds*>(mhx_lds_raw);
   lds_begin(lds);
@@ -1783,7 +1801,11 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
   const int w = wave_in_group(), l = lane_id(), d = P.d;
   // wave slot -> chain (ChainState::slot_chain: the chains still walking, packed)
   // (PERSIST: the one wave of this workgroup that got here is the master of chain blockIdx.y)
-  const int64_t slot = PERSIST ? (int64_t)blockIdx.y : (int64_t)blockIdx.x * kWavesPerGroup + w;
+  // (PERSIST: the chain's master wave of k_persist - chain blockIdx.y in the per-chain form,
+  // wave w of the master workgroup of chain group `group` in the tile-sliced form)
+  const int64_t slot = group >= 0 ? group * kWavesPerGroup + w
+                                  : (PERSIST ? (int64_t)blockIdx.y
+                                             : (int64_t)blockIdx.x * kWavesPerGroup + w);
   const bool in_range = slot < (S.slot_chain ? S.n_slots : S.n_chains);
   const int64_t mapped =
       in_range && S.slot_chain ? (int64_t)__builtin_amdgcn_readfirstlane(S.slot_chain[slot]) : slot;
@@ -1812,6 +1834,18 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
   }
 #endif
 
+  // PERSIST: the next iteration's random numbers are drawn while this one's partial sums are on
+  // their way (the draw counter does not depend on the accept decision), and the proposal factor
+  // waits in LDS (the master's workgroup stages no tiles), re-read after every change
+  double rv_pre = 0.0, lg_pre = 0.0;
+  bool have_pre = false, l_stale = true, stop_sent = false;
+  (void)stop_sent;
+  // (one copy per master wave of the workgroup where they all fit, else the factor stays in HBM)
+  const bool l_in_lds = PERSIST && (group < 0 ? 1 : kWavesPerGroup) * d * d * sizeof(double) <= sizeof(lds.tiles);
+  double* const l_lds = &lds.tiles[0][0][0] + (group < 0 ? 0 : w * d * d);
+  static_assert(!PERSIST || sizeof(lds.tiles) >= sizeof(double) * kPersistMaxParams * kPersistMaxParams,
+                "the proposal factor of the persistent kernel's master waits in the tile buffers");
+  (void)rv_pre; (void)lg_pre; (void)have_pre; (void)l_stale; (void)l_lds; (void)l_in_lds;
   for (int64_t it = 0; (SPLIT && !PERSIST) || it < max_iters; ++it) {
     MHX_TIM(lds, 6);
     MHX_TIMC(lds, 7);
@@ -1862,6 +1896,14 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     if constexpr (SPLIT) {
       if (valid && l == 0) S.split_pending[c] = 0;
     }
+    if constexpr (PERSIST) {
+      // a chain that has stopped walking says so at once: its sweep waves (tile-sliced form: the
+      // group's other chains go on) must not wait for a proposal that will never come
+      if (valid && !running && !stop_sent) {
+        persist_publish(S, c, 0, 0.0, kPersistStop);
+        stop_sent = true;
+      }
+    }
     // (the vote is the same in every lane; as a scalar it keeps the loop's exit - and so every
     // counter of the chain that lives across it - out of the vector registers)
     // One barrier and a flag per iteration (the library's __syncthreads_or is a workgroup
@@ -1899,13 +1941,27 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
       }
       // M:918 walker-take-step: proposal
       MHX_TIMC(lds, 0);
-      double lg;
-      const double rv = rng_lane_value(S.seed, gchain, r.draw, d, &lg);
+      double lg, rv;
+      if (PERSIST && have_pre) {
+        rv = rv_pre;
+        lg = lg_pre;
+      } else {
+        rv = rng_lane_value(S.seed, gchain, r.draw, d, &lg);
+      }
       r.draw++;
       // (the fused kernel carries log u to the accept test, split mode u itself)
-      u = SPLIT ? readlane_f64(rv, 63) : readlane_f64(lg, 63);
+      u = (SPLIT && !PERSIST) ? readlane_f64(rv, 63) : readlane_f64(lg, 63);
       MHX_TIMC(lds, 1);
-      thp = propose(Lc, d, rv, cur_in_lds ? (l < d ? lds.cur[w][l] : 0.0) : chain_theta(S, c, d));
+      if (PERSIST && l_in_lds) {
+        if (l_stale) {
+          for (int e = l; e < d * d; e += kWave) l_lds[e] = Lc[e];
+          __builtin_amdgcn_wave_barrier();
+          l_stale = false;
+        }
+        thp = propose(l_lds, d, rv, cur_in_lds ? (l < d ? lds.cur[w][l] : 0.0) : chain_theta(S, c, d));
+      } else {
+        thp = propose(Lc, d, rv, cur_in_lds ? (l < d ? lds.cur[w][l] : 0.0) : chain_theta(S, c, d));
+      }
       if (l < d) lds.prop[w][l] = thp;
       MHX_TIMC(lds, 2);
     }
@@ -1920,7 +1976,11 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
       break;
     }
     if constexpr (PERSIST) {  // ... to the chain's sweep workgroups of this same launch
-      if (running) persist_publish(S, c, d, thp, (unsigned long long)(it + 1));
+      if (running) {
+        persist_publish(S, c, d, thp, (unsigned long long)(it + 1));
+        rv_pre = rng_lane_value(S.seed, gchain, r.draw, d, &lg_pre);  // (the next iteration's)
+        have_pre = true;
+      }
     }
     }  // !resumed
     double ll, lp;
@@ -1963,8 +2023,8 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
       // across the sweep)
       const bool take =
           __builtin_amdgcn_readfirstlane(
-              (int)(SPLIT ? mh_accept(prob1, r.prob0, r.T, u)
-                          : mh_accept_log(prob1, r.prob0, r.T, u))) != 0;
+              (int)((SPLIT && !PERSIST) ? mh_accept(prob1, r.prob0, r.T, u)
+                                        : mh_accept_log(prob1, r.prob0, r.T, u))) != 0;
       if (take) r.prob0 = prob1;
       MHX_TIMC(lds, 4);
       const double th_now = take ? (l < d ? lds.prop[w][l] : 0.0)
@@ -1994,6 +2054,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
       const bool m200 = floor_mod(i, 200) == 0;
       const bool msts = !r.shutting && floor_mod(i, 2 * R.sts) == 0;
       if (m200 || msts) {
+        l_stale = true;  // (PERSIST: the factor may change below)
         __threadfence();
         ring.nh = r.nh;
         ring.length = r.length;
@@ -2155,58 +2216,126 @@ __global__ __launch_bounds__(kThreads) void k_split_step(const ProblemDesc* __re
 // polling that count - judges the proposal.  Every poll loop gives up after kPersistPatience
 // polls (the master then freezes the chain and raises the stop word, which ends the sweep
 // workgroups): no wave can spin for ever.
-template <class Spec>
-__device__ __forceinline__ void k_persist_body(const ProblemDesc* __restrict__ Pp, ChainState S,
-                                               RunDesc R, int64_t max_iters, int plain) {
-  const int64_t c = blockIdx.y;
-  if (blockIdx.x == 0) {
-    if (wave_in_group() != 0) return;  // (s_barrier counts the waves still alive)
-    k_adaptive_body<Spec, true, true>(Pp, S, R, max_iters, plain, 1);
-    persist_publish(S, c, 0, 0.0, kPersistStop);
-    return;
+// the master's next word for chain c: the proposal of generation `round + 1` (lane q of *word: the
+// q-th word of the chain's block), or stop.  false: stop, or patience ran out.
+__device__ __forceinline__ bool persist_poll(const ChainState& S, int64_t c, int d,
+                                             unsigned long long round, unsigned long long* word) {
+  const unsigned long long* msg = S.persist_msg + c * 64;
+  const int l = lane_id();
+  const int nlines = (d + 14) / 15;  // lines of the block that carry parameters
+  unsigned long long q = 0;
+  bool ok = false;
+  for (unsigned n = 0; n < kPersistPatience; ++n) {
+    q = __hip_atomic_load(msg + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool is_tag = (l & 15) == 15 && (l >> 4) < nlines;
+    unsigned f = (l & 15) != 15 ? persist_fold(q) : 0u;
+    f ^= (unsigned)__shfl_xor((int)f, 1, kWave);
+    f ^= (unsigned)__shfl_xor((int)f, 2, kWave);
+    f ^= (unsigned)__shfl_xor((int)f, 4, kWave);
+    f ^= (unsigned)__shfl_xor((int)f, 8, kWave);
+    // (lane 16 i + 15 now holds the fold of line i's data words - its own contribution was 0)
+    const unsigned gen = (unsigned)q;
+    const bool fresh = gen > (unsigned)round && (unsigned)(q >> 32) == f;
+    const unsigned long long bad = __ballot(is_tag && !fresh);
+    if (__builtin_amdgcn_readfirstlane((int)(bad == 0ull))) {
+      ok = true;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
   }
-  SweepLds& sl = *reinterpret_cast<SweepLds*>(mhx_lds_raw);
+  const unsigned gen0 = (unsigned)__builtin_amdgcn_readlane((int)q, 15);
+  *word = q;
+  return ok && !(gen0 & (unsigned)kPersistStop);
+}
+// TS = false: a handful of chains, grid (1 + slices, chains): workgroup (0, c) keeps only its wave
+// 0, the chain's master; workgroups (1 .., c) are the chain's sweep workgroups, wave w of workgroup
+// g the slot (g - 1) * waves + w of k_split_sweep.
+// TS = true: the tile-sliced mode (8 ... a few hundred chains), grid (1 + slices, groups): the 8
+// waves of workgroup (0, b) are the masters of chain group b's chains; workgroup (1 + g, b) walks
+// slice g with the group's proposals through sweep() exactly as k_split_tsweep does - LDS tiles
+// shared by the group, skipping, recurrence - round after round: every wave waits for ITS
+// chain's next proposal, the sweep's own barriers bring the group together, every wave hands its
+// chain's partial sum back as a {sum, round} pair.  A chain whose master has said stop leaves its
+// wave helping with the tiles (active = false) until the group's last chain is through.
+template <class Spec, bool TS>
+__device__ __forceinline__ void k_persist_body(const ProblemDesc* __restrict__ Pp,
+                                               const FnDesc* __restrict__ slices, ChainState S,
+                                               RunDesc R, int n_slices, int64_t max_iters,
+                                               int plain) {
   const ProblemDesc& P = *Pp;
   const int w = wave_in_group(), l = lane_id(), d = P.d;
-  lds_tables_begin();
-  __syncthreads();
-  const int slot = ((int)blockIdx.x - 1) * kWavesPerGroup + w;
-  const unsigned long long* msg = S.persist_msg + c * 64;
-  const int nlines = (d + 14) / 15;  // lines of the block that carry parameters
-  for (unsigned long long it = 0;; ++it) {
-    // the master's next word: the proposal of generation it + 1, or stop.  Every wave polls for
-    // itself (no barrier in this loop: the waves of a sweep workgroup run independently).
-    unsigned long long q = 0;
-    bool ok = false;
-    for (unsigned n = 0; n < kPersistPatience; ++n) {
-      q = __hip_atomic_load(msg + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool is_tag = (l & 15) == 15 && (l >> 4) < nlines;
-      const unsigned long long stale = __ballot(is_tag && q <= it);
-      if (__builtin_amdgcn_readfirstlane((int)(stale == 0ull))) {
-        ok = true;
-        break;
+  // this wave's chain: blockIdx.y itself, or through the group's slot -> chain map
+  int64_t c = blockIdx.y;
+  bool valid = true;
+  if constexpr (TS) {
+    const int64_t slot = (int64_t)blockIdx.y * kWavesPerGroup + w;
+    const bool in_range = slot < (S.slot_chain ? S.n_slots : S.n_chains);
+    const int64_t mapped =
+        in_range && S.slot_chain ? (int64_t)__builtin_amdgcn_readfirstlane(S.slot_chain[slot]) : slot;
+    valid = in_range && mapped >= 0;
+    c = valid ? mapped : 0;
+  }
+  if (blockIdx.x == 0) {
+    if (!TS && w != 0) return;  // (s_barrier counts the waves still alive)
+    k_adaptive_body<Spec, true, true>(Pp, S, R, max_iters, plain, 1, TS ? (int64_t)blockIdx.y : -1);
+    if (valid) persist_publish(S, c, 0, 0.0, kPersistStop);
+    return;
+  }
+  if constexpr (!TS) {
+    SweepLds& sl = *reinterpret_cast<SweepLds*>(mhx_lds_raw);
+    lds_tables_begin();
+    __syncthreads();
+    const int slot = ((int)blockIdx.x - 1) * kWavesPerGroup + w;
+    // Every wave polls for itself (no barrier in this loop: the waves of a sweep workgroup run
+    // independently).
+    for (unsigned long long it = 0;; ++it) {
+      unsigned long long q;
+      if (!persist_poll(S, c, d, it, &q)) return;
+      if ((l & 15) != 15 && (l >> 4) < (d + 14) / 15)
+        sl.prop[w][(l >> 4) * 15 + (l & 15)] = __longlong_as_double((long long)q);
+      __builtin_amdgcn_wave_barrier();
+      const double* th = sl.prop[w];
+      for (int k = 0; k < P.K; ++k) {
+        const FnDesc& f = P.fn[k];
+        auto pf = [&](int j) -> double { return th[f.idx[j]]; };
+        const int64_t pairs = (f.n + 2 * kWave - 1) / (2 * kWave);
+        const int64_t per = (pairs + S.split_slots - 1) / S.split_slots;
+        const int64_t b0 = (int64_t)slot * per, b1 = b0 + per < pairs ? b0 + per : pairs;
+        double v = 0.0;
+        if (b0 < b1) v = Spec::loglik_part(f, pf, b0 * 2 * kWave, b1 * 2 * kWave, sl.scr[w]);
+        if (l == 0)
+          persist_store_pair((char*)S.persist_part + (((size_t)c * P.K + k) * S.split_slots + slot) * 16, v,
+                             it + 1);
       }
-      __builtin_amdgcn_s_sleep(1);
     }
-    const unsigned long long tag0 =
-        ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(q >> 32), 15) << 32) |
-        (unsigned)__builtin_amdgcn_readlane((int)q, 15);
-    if (!ok || (tag0 & kPersistStop)) return;
-    if ((l & 15) != 15 && (l >> 4) < nlines)
-      sl.prop[w][(l >> 4) * 15 + (l & 15)] = __longlong_as_double((long long)q);
-    __builtin_amdgcn_wave_barrier();
-    const double* th = sl.prop[w];
-    for (int k = 0; k < P.K; ++k) {
-      const FnDesc& f = P.fn[k];
-      auto pf = [&](int j) -> double { return th[f.idx[j]]; };
-      const int64_t pairs = (f.n + 2 * kWave - 1) / (2 * kWave);
-      const int64_t per = (pairs + S.split_slots - 1) / S.split_slots;
-      const int64_t b0 = (int64_t)slot * per, b1 = b0 + per < pairs ? b0 + per : pairs;
-      double v = 0.0;
-      if (b0 < b1) v = Spec::loglik_part(f, pf, b0 * 2 * kWave, b1 * 2 * kWave, sl.scr[w]);
-      if (l == 0)
-        persist_store_pair((char*)S.persist_part + (((size_t)c * P.K + k) * S.split_slots + slot) * 16, v,
-                           it + 1);
+  } else {
+    GroupLds& lds = *reinterpret_cast<GroupLds*>(mhx_lds_raw);
+    lds_begin(lds);
+    const int slice = (int)blockIdx.x - 1;
+    bool alive = valid;
+    for (unsigned long long round = 0;; ++round) {
+      unsigned long long q = 0;
+      if (alive) alive = persist_poll(S, c, d, round, &q);
+      const bool active = alive;
+      // anybody of the group still walking?  (a flag and ONE barrier, as in k_adaptive_body)
+      const int vp = (int)(round % 3);
+      if (active && l == 0) lds.vote[vp] = 1;
+      if (active && (l & 15) != 15 && (l >> 4) < (d + 14) / 15)
+        lds.prop[w][(l >> 4) * 15 + (l & 15)] = __longlong_as_double((long long)q);
+      __syncthreads();
+      const int any = __builtin_amdgcn_readfirstlane(*(volatile int*)&lds.vote[vp]);
+      if (threadIdx.x == 0) lds.vote[(vp + 2) % 3] = 0;
+      if (!any) return;
+      const double* th = lds.prop[w];
+      for (int k = 0; k < P.K; ++k) {
+        const FnDesc& f = slices[k * n_slices + slice];
+        auto pf = [&](int j) -> double { return th[f.idx[j]]; };
+        const double v = Spec::loglik(f, pf, active, lds, lds.prm[w]);
+        const double raw = f.lik == MHX_LIK_NORMAL ? -2.0 * v : v;  // (as k_split_tsweep)
+        if (active && l == 0)
+          persist_store_pair((char*)S.persist_part + (((size_t)c * P.K + k) * S.split_slots + slice) * 16,
+                             raw, round + 1);
+      }
     }
   }
 }
@@ -2214,7 +2343,14 @@ template <class Spec>
 __global__ __launch_bounds__(kThreads) void k_persist(const ProblemDesc* __restrict__ Pp,
                                                       ChainState S, RunDesc R, int64_t max_iters,
                                                       int plain) {
-  k_persist_body<Spec>(Pp, S, R, max_iters, plain);
+  k_persist_body<Spec, false>(Pp, nullptr, S, R, 0, max_iters, plain);
+}
+template <class Spec>
+__global__ __launch_bounds__(kThreads) void k_persist_ts(const ProblemDesc* __restrict__ Pp,
+                                                         const FnDesc* __restrict__ slices,
+                                                         ChainState S, RunDesc R, int n_slices,
+                                                         int64_t max_iters, int plain) {
+  k_persist_body<Spec, true>(Pp, slices, S, R, n_slices, max_iters, plain);
 }
 
 // Initial L of M:896-901 when the caller gave none.

@@ -69,6 +69,10 @@ struct Family {
   // chains), every workgroup resident at once (the caller checks)
   hipError_t (*persist)(int spec, hipStream_t st, const ProblemDesc* P, const ChainState& S,
                         const RunDesc& R, int slices, int64_t max_iters, int plain);
+  // ... the same for the tile-sliced mode (k_persist_ts): grid (1 + n_slices, chain groups)
+  hipError_t (*persist_ts)(int spec, hipStream_t st, const ProblemDesc* P, const FnDesc* slices,
+                           const ChainState& S, const RunDesc& R, int n_slices, int64_t max_iters,
+                           int plain);
 };
 
 const Family& family_w8();

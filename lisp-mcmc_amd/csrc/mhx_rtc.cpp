@@ -318,7 +318,11 @@ static std::string generate(const std::vector<UserExpr>& models,
          "  k_adaptive_body<UserSpec, true>(P, S, R, 1, plain, mode);\n}\n"
          "extern \"C\" __global__ __launch_bounds__(MHX_USER_THREADS) void mhx_user_persist(\n"
          "    const ProblemDesc* P, ChainState S, RunDesc R, int64_t max_iters, int plain) {\n"
-         "  k_persist_body<UserSpec>(P, S, R, max_iters, plain);\n}\n";
+         "  k_persist_body<UserSpec, false>(P, nullptr, S, R, 0, max_iters, plain);\n}\n"
+         "extern \"C\" __global__ __launch_bounds__(MHX_USER_THREADS) void mhx_user_persist_ts(\n"
+         "    const ProblemDesc* P, const FnDesc* slices, ChainState S, RunDesc R, int n_slices,\n"
+         "    int64_t max_iters, int plain) {\n"
+         "  k_persist_body<UserSpec, true>(P, slices, S, R, n_slices, max_iters, plain);\n}\n";
   return s.str();
 }
 
@@ -530,12 +534,18 @@ static int build_once(const std::vector<UserExpr>& models, const std::vector<Use
     if (he == hipSuccess)
       he = hipFuncSetAttribute(reinterpret_cast<const void*>(prog->f_persist),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)fam.lds_bytes);
+    if (he == hipSuccess)
+      he = hipModuleGetFunction(&prog->f_persist_ts, prog->module, "mhx_user_persist_ts");
+    if (he == hipSuccess)
+      he = hipFuncSetAttribute(reinterpret_cast<const void*>(prog->f_persist_ts),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)fam.lds_bytes);
     if (he != hipSuccess) {
       *err = std::string("split-mode module functions: ") + hipGetErrorString(he);
       return -1;
     }
     if (static_lds(prog->f_split_sweep) != 0 || static_lds(prog->f_split_step) != 0 ||
-        static_lds(prog->f_split_tsweep) != 0 || static_lds(prog->f_persist) != 0) {
+        static_lds(prog->f_split_tsweep) != 0 || static_lds(prog->f_persist) != 0 ||
+        static_lds(prog->f_persist_ts) != 0) {
       *err = "split-mode module functions have static LDS";
       return -1;
     }
@@ -663,6 +673,18 @@ hipError_t rtc_launch_persist(const UserProgram& p, hipStream_t st, const Proble
   RunDesc r = R;
   void* args[] = {(void*)&P, (void*)&s, (void*)&r, (void*)&max_iters, (void*)&plain};
   return hipModuleLaunchKernel(p.f_persist, 1u + (unsigned)slices, (unsigned)S.n_chains, 1,
+                               (unsigned)p.fam->threads, 1, 1, (unsigned)p.fam->lds_bytes, st, args,
+                               nullptr);
+}
+hipError_t rtc_launch_persist_ts(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                                 const FnDesc* slices, const ChainState& S, const RunDesc& R,
+                                 int n_slices, int64_t max_iters, int plain) {
+  ChainState s = S;
+  RunDesc r = R;
+  void* args[] = {(void*)&P, (void*)&slices, (void*)&s, (void*)&r, (void*)&n_slices,
+                  (void*)&max_iters, (void*)&plain};
+  return hipModuleLaunchKernel(p.f_persist_ts, 1u + (unsigned)n_slices,
+                               grid_for(p, S.slot_chain ? S.n_slots : S.n_chains), 1,
                                (unsigned)p.fam->threads, 1, 1, (unsigned)p.fam->lds_bytes, st, args,
                                nullptr);
 }

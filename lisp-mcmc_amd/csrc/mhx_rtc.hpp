@@ -35,7 +35,7 @@ struct UserProgram {
   hipFunction_t f_logpost = nullptr, f_init = nullptr, f_step = nullptr, f_adaptive = nullptr;
   hipFunction_t f_split_sweep = nullptr, f_split_step = nullptr;  // only with has_split
   hipFunction_t f_split_tsweep = nullptr;                         // (the tile-sliced sweep)
-  hipFunction_t f_persist = nullptr;                              // (the persistent split kernel)
+  hipFunction_t f_persist = nullptr, f_persist_ts = nullptr;      // (the persistent split kernels)
   bool has_split = false;
   const Family* fam = nullptr;  // the kernel family (workgroup shape) the module was built for
   std::string source, log;
@@ -93,5 +93,8 @@ hipError_t rtc_launch_adaptive(const UserProgram& p, hipStream_t st, const Probl
 hipError_t rtc_launch_persist(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                               const ChainState& S, const RunDesc& R, int slices, int64_t max_iters,
                               int plain);
+hipError_t rtc_launch_persist_ts(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
+                                 const FnDesc* slices, const ChainState& S, const RunDesc& R,
+                                 int n_slices, int64_t max_iters, int plain);
 
 }  // namespace mhx

@@ -421,7 +421,8 @@ def test_split_with_expression_likelihood(mhx):
     # proposal, so the comparison with mhx_logpost above is a comparison of the two sweeps)
 
 
-def test_tile_sliced_repacking_does_not_depend_on_how_the_host_chunks_its_calls(mhx):
+@pytest.mark.parametrize("persist_ts", [False, True], ids=["two_launches", "persistent"])
+def test_tile_sliced_repacking_does_not_depend_on_how_the_host_chunks_its_calls(mhx, persist_ts):
     """the tile-sliced mode regroups the partial sums when it repacks, so WHEN it
     repacks must be a function of the walk, not of the host's call sequence.  Repacking is
     considered only where the iterations since begin are a multiple of the portion length
@@ -432,9 +433,16 @@ def test_tile_sliced_repacking_does_not_depend_on_how_the_host_chunks_its_calls(
     chains, n = 72, 7000
     th0 = pb.perturbed(s.theta_star, chains, 0.01, seed=8)
     res = []
+    # (the persistent form - MHX_PERSIST_TS=1 - in its many short launches is also where a torn
+    # read of the handshake showed in round 4: one chain in 72 x 7000 iterations went another way)
     for chunk, count in ((600, True), (137, True), (1 << 40, False), (512, False)):
-        e, name = ts_engine(mhx, s, chains, None, seed=17)
-        assert "tsplit x" in name, name
+        if persist_ts:
+            os.environ["MHX_PERSIST_TS"] = "1"
+        try:
+            e, name = ts_engine(mhx, s, chains, None, seed=17)
+        finally:
+            os.environ.pop("MHX_PERSIST_TS", None)
+        assert "tsplit x" in name and ("persistent" in name) == persist_ts, name
         e.init_chains(th0)
         e.adaptive_begin(n, 10.0, 1)
         for _ in range(200):
@@ -606,3 +614,81 @@ def test_single_walker_step_time(mhx):
         e.close()
     print("single walker, 1e5 points: %.2f us per step persistent, %.2f us two launches" % tuple(out))
     assert out[0] <= out[1] * 1.05
+
+
+def ts_persist_pair(mhx, spec, chains, ts, **kw):
+    """(k_persist_ts - behind MHX_PERSIST_TS=1: built, bit-identical, not faster -, the two launches)"""
+    out = []
+    for flag in ("1", None):
+        if flag:
+            os.environ["MHX_PERSIST_TS"] = flag
+        try:
+            e, name = ts_engine(mhx, spec, chains, ts, **kw)
+        finally:
+            os.environ.pop("MHX_PERSIST_TS", None)
+        out.append((e, name))
+    assert "persistent tsplit x" in out[0][1] and "persistent" not in out[1][1] and "tsplit x" in out[1][1], \
+        [n for _, n in out]
+    return out[0][0], out[1][0]
+
+
+@pytest.mark.parametrize("name,make,lscale,chains,ask", TS_CASES, ids=[c[0] for c in TS_CASES])
+def test_persistent_tile_sliced_mode_equals_the_two_launch_form(mhx, name, make, lscale, chains, ask):
+    """VERDICT r3 item 6, the batches of 8 ... a few hundred walkers: ONE launch per portion of
+    iterations (k_persist_ts) - the 8 waves of a group's master workgroup run the chains'
+    controllers, the group's sweep workgroups walk their slices through sweep() round after
+    round, proposals and {sum, round} pairs handed over through memory.  Same slices, same sweep,
+    same order of the sums: bit for bit the two launches per iteration (MHX_NO_PERSIST=1) under
+    the same slicing - complete runs in uneven portions, chains ending at different times inside
+    a group, a last group that is not full, a second run, plain steps."""
+    s = make()
+    th0 = pb.perturbed(s.theta_star, chains, 0.01, seed=2)
+    l0 = None if lscale is None else np.diag(lscale * np.abs(s.theta_star))
+    a, b = ts_persist_pair(mhx, s, chains, ask if ask is not None else 5, seed=9)
+    res = []
+    for e in (a, b):
+        e.init_chains(th0)
+        e.adaptive_begin(2600, 10.0, 1, l_matrix=l0)
+        for portion in (3, 200, 1 << 40):
+            if e.adaptive_advance(portion) == 0:
+                break
+        first = (e.state(), e.chain_status()[0], e.lmatrix())
+        e.init_chains(th0)
+        e.adaptive_begin(500, 10.0, 1, l_matrix=l0)
+        e.adaptive_advance(1 << 40)
+        e.many_steps(45, np.diag(0.003 * np.abs(s.theta_star)))
+        res.append((first, (e.state(), e.chain_status()[0], e.lmatrix())))
+    for (sa, sta, La), (sb, stb, Lb) in zip(res[0], res[1]):
+        assert np.array_equal(sta, stb) and (sta == mhx.capi.CHAIN_DONE).all()
+        for k in ("theta", "logpost", "best_theta", "best_logpost", "age", "length"):
+            assert np.array_equal(sa[k], sb[k]), (name, k)
+        assert np.array_equal(La, Lb)
+    for e in (a, b):
+        e.close()
+
+
+def test_small_batch_iteration_time(mhx):
+    """64, 256 and 1024 walkers on config 2's 1e5 points: microseconds per iteration, the persistent
+    tile-sliced form (MHX_PERSIST_TS=1) against the default two launches (printed)"""
+    import time
+    big = pb.two_peak(n=100000, seed=3)
+    for chains in (64, 256, 1024):
+        out = []
+        for flag in ("1", None):
+            if flag:
+                os.environ["MHX_PERSIST_TS"] = flag
+            try:
+                e, name = ts_engine(mhx, big, chains, None, seed=9)
+            finally:
+                os.environ.pop("MHX_PERSIST_TS", None)
+            e.init_chains(pb.perturbed(big.theta_star, chains, 0.01, seed=2))
+            e.adaptive_begin(30000, 10.0, 1)
+            e.adaptive_advance(512)
+            t0 = time.perf_counter()
+            e.adaptive_advance(2048)
+            out.append(((time.perf_counter() - t0) / 2048 * 1e6, name))
+            e.close()
+        print("%d walkers, 1e5 points: %.2f us per iteration %s (%.3g chain-steps/s), %.2f us %s"
+              % (chains, out[0][0], out[0][1].split("/")[1], chains / out[0][0] * 1e6, out[1][0],
+                 out[1][1].split("/")[1]))
+        # (no assertion: the persistent tile-sliced form is not the default because it is not faster)
