@@ -190,13 +190,22 @@ int mhx_set_function(mhx_engine* e, int k, int model_id, const int32_t* shape, i
  * The engine copies.  For MHX_LIK_POISSON y holds the counts k_i and sigma is ignored. */
 int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y,
                     const double* sigma, size_t n, int likelihood);
+/* The same with a VECTOR-VALUED x: "multiple or linked independent variables" - the reference
+ * hands each element of the x list to the function as it is (M:400), and a closure reads its
+ * components with (elt x 0), (elt x 1) (M:1136-1137).  xcols[j][i] = component j of point i,
+ * n_cols 1 or 2.  Component 0 is the x of every enumerated model and of the windows' ranges;
+ * an expression function names the components xcol0 (= x) and xcol1.  Not with
+ * MHX_LIK_NORMAL_CUTOFF (MHX_EUNSUPPORTED). */
+int mhx_set_dataset_cols(mhx_engine* e, int k, const double* const* xcols, int n_cols,
+                         const double* y, const double* sigma, size_t n, int likelihood);
 /* prior-bounds-let block of function k (M:346-369): idx[i] < 0 means "key absent from
  * the plist" (getf default 0d0, M:353).  n == 0 -> log-prior-flat (M:340-343). */
 int mhx_set_bounds(mhx_engine* e, int k, const int32_t* idx, const double* lo,
                    const double* hi, int n);
 /* Function k given as an EXPRESSION: what a host shim makes of the body
  * of (lambda (x &key a b &allow-other-keys) <body>) (M:1134-1137).  `expr` is a C-syntax
- * arithmetic expression over `x`, the identifiers in param_names (local parameter j =
+ * arithmetic expression over `x` (with a vector-valued x, mhx_set_dataset_cols: `xcol0`, `xcol1`), the
+ * identifiers in param_names (local parameter j =
  * theta[param_index[j]]), numeric literals, + - * / ?: < <= > >= == != && || !, and the
  * functions exp log sqrt sin cos tan atan tanh abs pow min max.  It is compiled for gfx950
  * with hiprtc into the same fused kernels when the problem is finalised (first
@@ -312,6 +321,8 @@ int mhx_group_set_function(mhx_group* g, int k, int model_id, const int32_t* sha
                            const int32_t* param_index, int n_index);
 int mhx_group_set_dataset(mhx_group* g, int k, const double* x, const double* y,
                           const double* sigma, size_t n, int likelihood);
+int mhx_group_set_dataset_cols(mhx_group* g, int k, const double* const* xcols, int n_cols,
+                               const double* y, const double* sigma, size_t n, int likelihood);
 int mhx_group_set_bounds(mhx_group* g, int k, const int32_t* idx, const double* lo,
                          const double* hi, int n);
 int mhx_group_set_function_expr(mhx_group* g, int k, const char* expr,

@@ -51,6 +51,8 @@ SIGNATURES = {
     "mhx_destroy": (None, [C.c_void_p]),
     "mhx_set_function": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i32p, C.c_int, i32p, C.c_int]),
     "mhx_set_dataset": (C.c_int, [C.c_void_p, C.c_int, f64p, f64p, f64p, C.c_size_t, C.c_int]),
+    "mhx_set_dataset_cols": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(f64p), C.c_int, f64p, f64p,
+                                       C.c_size_t, C.c_int]),
     "mhx_set_bounds": (C.c_int, [C.c_void_p, C.c_int, i32p, f64p, f64p, C.c_int]),
     "mhx_set_function_expr": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_char_p),
                                         i32p, C.c_int]),
@@ -96,6 +98,8 @@ SIGNATURES = {
     "mhx_group_chain_range": (C.c_int, [C.c_void_p, C.c_int, i64p, i64p]),
     "mhx_group_set_function": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i32p, C.c_int, i32p, C.c_int]),
     "mhx_group_set_dataset": (C.c_int, [C.c_void_p, C.c_int, f64p, f64p, f64p, C.c_size_t, C.c_int]),
+    "mhx_group_set_dataset_cols": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(f64p), C.c_int, f64p, f64p,
+                                             C.c_size_t, C.c_int]),
     "mhx_group_set_bounds": (C.c_int, [C.c_void_p, C.c_int, i32p, f64p, f64p, C.c_int]),
     "mhx_group_set_function_expr": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p,
                                               C.POINTER(C.c_char_p), i32p, C.c_int]),

@@ -1275,6 +1275,14 @@ __device__ __forceinline__ typename M::Prep model_prepare(PF pf, const FnDesc& f
   if constexpr (model_wants_scratch<M>::value) return M::prepare(pf, fn, scratch);
   else return M::prepare(pf, fn);
 }
+// models that read a second column of x ("multiple or linked independent variables", M:1136-1137:
+// (elt x 0), (elt x 1)): expression models whose text names xcol1 - eval2(prep, xcol0, xcol1)
+template <class M, class = void>
+struct model_xcols { static constexpr int value = 1; };
+template <class M>
+struct model_xcols<M, decltype((void)M::kXCols, void())> {
+  static constexpr int value = M::kXCols;
+};
 template <class M, class = void>
 struct model_has_eval_n { static constexpr bool value = false; };
 template <class M>

@@ -609,6 +609,9 @@ int finalize_problem(mhx_engine* e) {
         return fail(MHX_EUNSUPPORTED, "function %d: an expression likelihood needs an expression "
                                       "model (mhx_set_function_expr)", k);
     }
+    if (f.model == MHX_MODEL_EXPR && e->fn_expr[k].xcols > f.n_xcols)
+      return fail(MHX_ESTATE, "function %d reads xcol1 but dataset %d has one column of x "
+                              "(mhx_set_dataset_cols)", k, k);
     any_expr = any_expr || f.model == MHX_MODEL_EXPR || !e->prior_expr[k].expr.empty();
   }
   // Which kernels: an ahead-of-time specialisation if the problem matches one; otherwise kernels
@@ -1494,13 +1497,17 @@ int mhx_set_function(mhx_engine* e, int k, int model_id, const int32_t* shape, i
   return MHX_OK;
 }
 
-int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y, const double* sigma,
-                    size_t n, int likelihood) {
+// x1: the second column of a vector-valued x (mhx_set_dataset_cols), or NULL
+static int set_dataset_impl(mhx_engine* e, int k, const double* x, const double* x1, const double* y,
+                            const double* sigma, size_t n, int likelihood) {
   if (!e) return fail(MHX_EINVAL, "engine is NULL");
   if (k < 0 || k >= e->P.K) return fail(MHX_EINVAL, "dataset index %d out of range", k);
   if (n > 0 && (!x || !y)) return fail(MHX_EINVAL, "x/y is NULL");
   if (likelihood < MHX_LIK_NORMAL || likelihood > MHX_LIK_EXPR)
     return fail(MHX_EINVAL, "unknown likelihood %d", likelihood);
+  if (x1 && likelihood == MHX_LIK_NORMAL_CUTOFF)
+    return fail(MHX_EUNSUPPORTED, "a second column of x with log-liklihood-normal-cutoff: the tiles' "
+                                  "fourth array is taken by the clamp's per-point constants");
   int rc = use_device(e);
   if (rc != MHX_OK) return rc;
   // padded to a whole number of tiles of either kernel family
@@ -1538,6 +1545,8 @@ int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y, cons
     hw[i] = 0.0;
     hc[i] = 0.0;
   }
+  if (x1)  // (the c array is read by the cutoff likelihood only, which was refused above)
+    for (size_t i = 0; i < np; ++i) hc[i] = n ? x1[i < n ? i : n - 1] : 0.0;
   Dataset& D = e->data[k];
   if (D.x.alloc(np, false) != hipSuccess || D.y.alloc(np, false) != hipSuccess ||
       D.w.alloc(np, false) != hipSuccess || D.c.alloc(np, false) != hipSuccess)
@@ -1568,6 +1577,7 @@ int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y, cons
   // x_0 + i h with h = (x_(n-1) - x_0) / (n - 1); MHX_NO_RECURRENCE=1 keeps the direct form.
   f.grid_H = 0.0;
   f.tgh = nullptr;  // (per-window grids: finalize_problem)
+  f.n_xcols = x1 ? 2 : 1;
   D.n = n;
   {
     const char* nr = getenv("MHX_NO_RECURRENCE");
@@ -1584,6 +1594,18 @@ int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y, cons
   D.set = true;
   e->problem_dirty = true;
   return MHX_OK;
+}
+
+int mhx_set_dataset(mhx_engine* e, int k, const double* x, const double* y, const double* sigma,
+                    size_t n, int likelihood) {
+  return set_dataset_impl(e, k, x, nullptr, y, sigma, n, likelihood);
+}
+
+int mhx_set_dataset_cols(mhx_engine* e, int k, const double* const* xcols, int n_cols,
+                         const double* y, const double* sigma, size_t n, int likelihood) {
+  if (!xcols || n_cols < 1 || n_cols > 2 || !xcols[0] || (n_cols == 2 && !xcols[1]))
+    return fail(MHX_EINVAL, "x must come as 1 or 2 columns (%d given)", n_cols);
+  return set_dataset_impl(e, k, xcols[0], n_cols == 2 ? xcols[1] : nullptr, y, sigma, n, likelihood);
 }
 
 int mhx_set_bounds(mhx_engine* e, int k, const int32_t* idx, const double* lo, const double* hi,
@@ -1604,11 +1626,22 @@ int mhx_set_bounds(mhx_engine* e, int k, const int32_t* idx, const double* lo, c
   return MHX_OK;
 }
 
+// does `expr` mention the identifier `id` (as a whole word)?
+static bool expr_names(const char* expr, const char* id) {
+  const size_t n = strlen(id);
+  for (const char* p = expr; (p = strstr(p, id)) != nullptr; p += n) {
+    const bool left = p == expr || !(isalnum((unsigned char)p[-1]) || p[-1] == '_');
+    const bool right = !(isalnum((unsigned char)p[n]) || p[n] == '_');
+    if (left && right) return true;
+  }
+  return false;
+}
 static bool valid_ident(const char* s) {
   if (!s || !(isalpha((unsigned char)s[0]) || s[0] == '_')) return false;
   for (const char* p = s; *p; ++p)
     if (!(isalnum((unsigned char)*p) || *p == '_')) return false;
-  return strcmp(s, "x") != 0 && strcmp(s, "bounds_total") != 0;
+  return strcmp(s, "x") != 0 && strcmp(s, "xcol0") != 0 && strcmp(s, "xcol1") != 0 &&
+         strcmp(s, "bounds_total") != 0;
 }
 
 int mhx_set_function_expr(mhx_engine* e, int k, const char* expr, const char* const* param_names,
@@ -1627,8 +1660,9 @@ int mhx_set_function_expr(mhx_engine* e, int k, const char* expr, const char* co
     u.index.push_back(param_index[j]);
   }
   std::string err;
-  if (rtc_prepare_expr(expr, u.names, "x", &u.expr, &err) != 0)
+  if (rtc_prepare_expr(expr, u.names, "x xcol0 xcol1", &u.expr, &err) != 0)
     return fail(MHX_EINVAL, "%s", err.c_str());
+  u.xcols = expr_names(expr, "xcol1") ? 2 : 1;
   FnDesc& f = e->P.fn[k];
   f.model = MHX_MODEL_EXPR;
   f.n_idx = n_index;
@@ -1653,7 +1687,7 @@ int mhx_expr_classify(const char* expr, const char* const* param_names, int n_na
     names.push_back(param_names[j]);
   }
   std::string out, err;
-  if (rtc_prepare_expr(expr, names, "x", &out, &err) != 0) return fail(MHX_EINVAL, "%s", err.c_str());
+  if (rtc_prepare_expr(expr, names, "x xcol0 xcol1", &out, &err) != 0) return fail(MHX_EINVAL, "%s", err.c_str());
   RecognisedModel r;
   (void)rtc_recognise(expr, names, &r);
   *model = r.model >= 0 ? r.model : MHX_MODEL_EXPR;
@@ -2524,6 +2558,10 @@ int mhx_group_set_function(mhx_group* g, int k, int model_id, const int32_t* sha
 int mhx_group_set_dataset(mhx_group* g, int k, const double* x, const double* y,
                           const double* sigma, size_t n, int likelihood) {
   MHX_GROUP_EACH(mhx_set_dataset(e, k, x, y, sigma, n, likelihood));  // replicated on every GPU
+}
+int mhx_group_set_dataset_cols(mhx_group* g, int k, const double* const* xcols, int n_cols,
+                               const double* y, const double* sigma, size_t n, int likelihood) {
+  MHX_GROUP_EACH(mhx_set_dataset_cols(e, k, xcols, n_cols, y, sigma, n, likelihood));
 }
 int mhx_group_set_bounds(mhx_group* g, int k, const int32_t* idx, const double* lo,
                          const double* hi, int n) {

@@ -379,7 +379,11 @@ template <class Model, int LIK, bool WG = false>
 __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::Prep& prep_in,
                                         bool active, GroupLds& lds, bool fast = false,
                                         unsigned rmask = 0u, bool bgrec = false) {
-  constexpr int NARR = LIK == MHX_LIK_POISSON ? 2 : (LIK == MHX_LIK_NORMAL_CUTOFF ? 4 : 3);
+  // a second column of x (model_xcols: expression models that name xcol1) rides in the tiles' fourth
+  // array, which only the cutoff likelihood uses otherwise (the host refuses that pair)
+  constexpr bool kX2 = model_xcols<Model>::value > 1;
+  static_assert(!(kX2 && LIK == MHX_LIK_NORMAL_CUTOFF), "the fourth tile array is taken");
+  constexpr int NARR = kX2 ? 4 : (LIK == MHX_LIK_POISSON ? 2 : (LIK == MHX_LIK_NORMAL_CUTOFF ? 4 : 3));
   constexpr bool kWinGrid = WG;
   static_assert(!WG || (model_has_rec<Model>::value && model_has_skip<Model>::value), "regrid");
   typename PickType<WG, typename Model::Prep, const typename Model::Prep&>::type prep = prep_in;
@@ -664,6 +668,9 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
               } else {
                 model_eval_n<Model, FAST, P>(prep, x, mask, m);
               }
+            } else if constexpr (kX2) {
+#pragma unroll
+              for (int i = 0; i < P; ++i) m[i] = Model::eval2(prep, x[i], cv[i]);
             } else {
               model_eval_n<Model, FAST, P>(prep, x, mask, m);
             }
@@ -823,8 +830,15 @@ __device__ __forceinline__ double sweep_direct(const FnDesc& f, const typename M
     const double x0 = f.x[i0], x1 = f.x[i1], y0 = f.y[i0], y1 = f.y[i1];
     double w0 = 0.0, w1 = 0.0, c0 = 0.0, c1 = 0.0;
     if constexpr (LIK != MHX_LIK_POISSON) { w0 = f.w[i0]; w1 = f.w[i1]; }
-    if constexpr (LIK == MHX_LIK_NORMAL_CUTOFF) { c0 = f.c[i0]; c1 = f.c[i1]; }
-    const double m0 = model_eval<Model, FAST>(prep, x0), m1 = model_eval<Model, FAST>(prep, x1);
+    if constexpr (LIK == MHX_LIK_NORMAL_CUTOFF || model_xcols<Model>::value > 1) { c0 = f.c[i0]; c1 = f.c[i1]; }
+    double m0, m1;
+    if constexpr (model_xcols<Model>::value > 1) {  // (the second column of x sits in the c array)
+      m0 = Model::eval2(prep, x0, c0);
+      m1 = Model::eval2(prep, x1, c1);
+    } else {
+      m0 = model_eval<Model, FAST>(prep, x0);
+      m1 = model_eval<Model, FAST>(prep, x1);
+    }
     if constexpr (LIK == MHX_LIK_NORMAL) {
       const double r0 = __builtin_fma(-m0, w0, y0), r1 = __builtin_fma(-m1, w1, y1);
       acc0 = __builtin_fma(r0, r0, acc0);

@@ -206,12 +206,18 @@ static std::string generate(const std::vector<UserExpr>& models,
       << "    Prep q;\n";
     for (int j = 0; j < np; ++j) s << "    q.p[" << j << "] = uniform_f64(pf(" << j << "));\n";
     s << "    return q;\n  }\n"
-      << "  static __device__ __forceinline__ double eval(const Prep& q, double x) {\n"
-      << (recip ? "#pragma clang fp reciprocal(on)\n" : "");
+      // xcol0 is x; xcol1 the dataset's second column (mhx_set_dataset_cols), which the sweep hands
+      // over only to models that say they read it (kXCols)
+      << "  static __device__ __forceinline__ double eval2(const Prep& q, double x, double xcol1) {\n"
+      << (recip ? "#pragma clang fp reciprocal(on)\n" : "")
+      << "    const double xcol0 = x; (void)xcol0; (void)xcol1;\n";
     for (int j = 0; j < np; ++j)
       s << "    const double p_" << u.names[j] << " = q.p[" << j << "]; (void)p_" << u.names[j]
         << ";\n";
-    s << "    return (double)(" << u.expr << ");\n  }\n";
+    s << "    return (double)(" << u.expr << ");\n  }\n"
+      << "  static __device__ __forceinline__ double eval(const Prep& q, double x) {"
+         " return eval2(q, x, 0.0); }\n";
+    if (u.xcols > 1) s << "  static constexpr int kXCols = " << u.xcols << ";\n";
     if (!u.lik_expr.empty())
       s << "  static __device__ __forceinline__ double lik_term(double y, double model, double error) {\n"
         << "    (void)y; (void)model; (void)error;\n"

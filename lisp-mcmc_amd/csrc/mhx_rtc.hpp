@@ -24,6 +24,7 @@ struct UserExpr {
   std::string builtin;   // models: non-empty = the C++ type of an ahead-of-time model struct
                          // ("PeaksModel<1, 3, false>"): no expression, the function is only
                          // given its own compile-time specialisation
+  int xcols = 1;         // expression models: 2 when the text names xcol1 (a second column of x)
   bool wgrid = false;    // builtin peaks models: the function has a per-window grid table
                          // (FnDesc::tgh) - its kernel is FixedSpec<Model, LIK, true>
   int lik = -1;          // models: the function's likelihood kind (-1: dispatch at run time)

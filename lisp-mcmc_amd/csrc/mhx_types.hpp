@@ -55,7 +55,7 @@ struct FnDesc {
   int32_t user_slot;  // >= 0: index of the run-time compiled expression model (MHX_MODEL_EXPR)
   int32_t prior_slot; // >= 0: index of the run-time compiled prior body, else -1
   int32_t no_yw;      // 1: never take the two-array "yw" tiles of the all-recurrence steps (MHX_NO_YW=1)
-  int32_t pad_;
+  int32_t n_xcols;    // columns of x the dataset brought (mhx_set_dataset_cols): with 2, c holds x1
   // per-window grids: [ceil(n / kPadPoints)] 64 h of every 2048-point window whose x are a grid
   // x_w + i h (to 8 ulp of its max |x|), 0 where they are not; nullptr when the WHOLE dataset is
   // one grid (grid_H != 0) or no window is.  Runs of windows on one grid carry the same bits.

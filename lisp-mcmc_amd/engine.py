@@ -66,10 +66,21 @@ class Engine:
         capi.check(capi.lib().mhx_set_likelihood_expr(self._h, k, expr.encode()))
 
     def set_dataset(self, k, x, y, sigma=None, likelihood=capi.LIK_NORMAL):
+        """x: [n], or [n][2] - a vector-valued x, one row per point, as the reference's x list holds
+        it (mcmc-fitting.lisp:1136-1137): mhx_set_dataset_cols"""
         xa, xp = capi.as_f64(x)
         ya, yp = capi.as_f64(y)
+        if xa.ndim == 2 and xa.shape[0] == ya.shape[0] and ya.ndim == 1:
+            cols = [np.ascontiguousarray(xa[:, j]) for j in range(xa.shape[1])]
+            ptrs = (capi.f64p * len(cols))(*[c.ctypes.data_as(capi.f64p) for c in cols])
+            sp = None
+            if sigma is not None:
+                sa, sp = capi.as_f64(np.broadcast_to(np.asarray(sigma, dtype=np.float64), ya.shape))
+            capi.check(capi.lib().mhx_set_dataset_cols(self._h, k, ptrs, len(cols), yp, sp, ya.size,
+                                                       likelihood))
+            return
         if xa.shape != ya.shape or xa.ndim != 1:
-            raise ValueError("x and y must be 1-d and of equal length")
+            raise ValueError("x and y must be 1-d and of equal length (or x [n][2])")
         if sigma is None:
             sp = None
         else:

@@ -59,6 +59,9 @@ library, or without a gfx950 device, walker-create signals MHX-ERROR."
   (param-index :pointer) (n-index :int))
 (cffi:defcfun ("mhx_set_dataset" %mhx-set-dataset) :int
   (e :pointer) (k :int) (x :pointer) (y :pointer) (sigma :pointer) (n :size) (likelihood :int))
+(cffi:defcfun ("mhx_set_dataset_cols" %mhx-set-dataset-cols) :int
+  (e :pointer) (k :int) (xcols :pointer) (n-cols :int) (y :pointer) (sigma :pointer) (n :size)
+  (likelihood :int))
 (cffi:defcfun ("mhx_set_bounds" %mhx-set-bounds) :int
   (e :pointer) (k :int) (idx :pointer) (lo :pointer) (hi :pointer) (n :int))
 (cffi:defcfun ("mhx_set_function_expr" %mhx-set-function-expr) :int
@@ -137,6 +140,9 @@ library, or without a gfx950 device, walker-create signals MHX-ERROR."
   (param-index :pointer) (n-index :int))
 (cffi:defcfun ("mhx_group_set_dataset" %mhx-group-set-dataset) :int
   (g :pointer) (k :int) (x :pointer) (y :pointer) (sigma :pointer) (n :size) (likelihood :int))
+(cffi:defcfun ("mhx_group_set_dataset_cols" %mhx-group-set-dataset-cols) :int
+  (g :pointer) (k :int) (xcols :pointer) (n-cols :int) (y :pointer) (sigma :pointer) (n :size)
+  (likelihood :int))
 (cffi:defcfun ("mhx_group_set_bounds" %mhx-group-set-bounds) :int
   (g :pointer) (k :int) (idx :pointer) (lo :pointer) (hi :pointer) (n :int))
 (cffi:defcfun ("mhx_group_set_function_expr" %mhx-group-set-function-expr) :int

@@ -79,6 +79,14 @@
                                    (cdr a) :initial-value (tr (first a))))
                           (if (format nil "((~a) ? ~a : ~a)" (test (first a)) (tr (second a))
                                       (if (cddr a) (tr (third a)) "0.0")))
+                          ;; (elt x 0), (elt x 1), (aref x 1): the components of a vector-valued
+                          ;; independent variable (mcmc-fitting.lisp:1136-1137) - columns xcol0,
+                          ;; xcol1 of mhx_set_dataset_cols
+                          ((elt aref svref)
+                           (if (and (symbolp (first a)) (equal (sym (first a)) "x") (integerp (second a)))
+                               (format nil "xcol~d" (second a))
+                               (error 'mhx-error :code -5
+                                                 :message (format nil "~s: only a literal index into the independent variable" f))))
                           (the (tr (second a)))
                           ((coerce float) (tr (first a)))
                           (t (let ((fn (cdr (assoc op *unary-functions*))))

@@ -165,6 +165,10 @@ def to_c(form, rename=None):
             # under the one key `params`; the host expands such a key into params_0, params_1...
             seq, ix = (a[1], a[0]) if op == "nth" else (a[0], a[1])
             if isinstance(seq, str) and isinstance(ix, str) and ix.isdigit():
+                # (elt x 0), (elt x 1): the components of a vector-valued independent variable
+                # (M:1136-1137) - columns xcol0, xcol1 of mhx_set_dataset_cols
+                if sym(seq) == "x":
+                    return "xcol" + ix
                 return sym(seq) + "_" + ix
             raise SexprError("%s needs a literal index into a parameter sequence" % op)
         if op in ("the", "coerce", "float") and len(a) >= 2:

@@ -109,7 +109,22 @@ def _depth(t):  # get-depth M:761-772
     return 1 + _depth(t[0])
 
 
+def _vector_x(ds):
+    """a dataset [X, y] whose x elements are vectors - "multiple or linked independent variables",
+    M:1136-1137: X [n][2] (one row per point), y [n]"""
+    try:
+        return (len(ds) == 2 and np.ndim(ds[0]) == 2 and np.ndim(ds[1]) == 1
+                and np.shape(ds[0])[0] == np.shape(ds[1])[0] and np.shape(ds[0])[1] in (1, 2)
+                and np.shape(ds[0])[0] != 2)
+    except (TypeError, ValueError):
+        return False
+
+
 def _clean_data(data, n_fn):  # M:807-825
+    if _vector_x(data):
+        return _clean_data([data], n_fn)
+    if len(data) == n_fn and all(_vector_x(ds) for ds in data):
+        return [[np.asarray(ds[0], dtype=np.float64), np.asarray(ds[1], dtype=np.float64)] for ds in data]
     dep = _depth(data)
     if dep == 1:
         raise ValueError("clean-data: data is of insufficient depth or improperly structured.")

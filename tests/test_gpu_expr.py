@@ -302,3 +302,84 @@ def test_recognised_peak_closure_runs_on_the_peak_kernels(mhx, orc):
     wp = mhx.walker_create(function=mhx.models.lisp(TWO_PEAK), data=[x, y], params=perm, data_error=sig,
                            n_chains=3, seed=5)
     assert "gauss22_normal" in wp.engine.kernel_name() and wp.last_step().prob == p[0]
+
+
+def test_vector_valued_x_plane_fit(mhx):
+    """"multiple or linked independent variables" (mcmc-fitting.lisp:1136-1137):
+    each element of the x list is a vector and the closure reads (elt x 0), (elt x 1).  A plane
+    z = a + b x0 + c x1 + d x0 x1 with per-point sigma through mhx_set_dataset_cols (the second
+    column rides in the tiles' fourth array): log-posteriors against numpy within the stated
+    tolerance, batch kernels and split mode, and a walk that recovers the plane; the weighted
+    Poisson form with a custom likelihood; what is refused."""
+    rng = np.random.default_rng(21)
+    n = 5000
+    X = np.column_stack([rng.uniform(-1, 2, n), rng.uniform(0, 3, n)])
+    tstar = np.array([0.4, 1.3, -0.7, 0.25])
+    sig = rng.uniform(0.05, 0.2, n)
+
+    def plane(t, X):
+        return t[0] + t[1] * X[:, 0] + t[2] * X[:, 1] + t[3] * X[:, 0] * X[:, 1]
+    z = plane(tstar, X) + sig * rng.standard_normal(n)
+    text = ("(lambda (x &key a b c d &allow-other-keys)"
+            " (+ a (* b (elt x 0)) (* c (elt x 1)) (* d (elt x 0) (aref x 1))))")
+    keys, cexpr = mhx.sexpr.lambda_to_expr(text)
+    assert keys == ["a", "b", "c", "d"] and "xcol0" in cexpr and "xcol1" in cexpr
+    params = [":a", 0.3, ":b", 1.0, ":c", -0.5, ":d", 0.2]
+    w = mhx.walker_create(function=mhx.models.lisp(text), data=[X, z], params=params, data_error=sig,
+                          n_chains=5, seed=4)
+    assert "rtc[expr" in w.engine.kernel_name()
+    th = np.array([[0.3, 1.0, -0.5, 0.2], tstar, tstar * 1.1, [0, 0, 0, 0], [1, -1, 2, 0.5]])
+    got = w.engine.logpost(th)
+    for i, t in enumerate(th):
+        terms = -0.5 * np.log(2 * np.pi) - np.log(sig) - 0.5 * ((z - plane(t, X)) / sig) ** 2
+        assert abs(got[i] - terms.sum()) <= REL * np.abs(terms).sum(), i
+    mhx.walker_adaptive_steps(w, 4000)
+    ml = mhx.walker_get(w, get=":most-likely-params")
+    assert max(abs(ml[k] - v) for k, v in zip("abcd", tstar)) < 0.05, ml
+    # split mode (a single walker on a long dataset): the same sums to rounding
+    n2 = 60000
+    X2 = np.column_stack([rng.uniform(-1, 2, n2), rng.uniform(0, 3, n2)])
+    s2 = rng.uniform(0.05, 0.2, n2)
+    z2 = plane(tstar, X2) + s2 * rng.standard_normal(n2)
+    import os
+    ws = []
+    for split in ("0", None):
+        if split is None:
+            os.environ.pop("MHX_SPLIT", None)
+        else:
+            os.environ["MHX_SPLIT"] = split
+        try:
+            ws.append(mhx.walker_create(function=mhx.models.lisp(text), data=[X2, z2], params=params,
+                                        data_error=s2, seed=4))
+            ws[-1].engine.kernel_name()
+        finally:
+            os.environ["MHX_SPLIT"] = "0"
+    assert "split x" in ws[1].engine.kernel_name() and "split" not in ws[0].engine.kernel_name()
+    for w2 in ws:
+        mhx.walker_adaptive_steps_full(w2, n=300, temperature=10, auto=":prob-settle",
+                                       l_matrix=np.diag([0.01] * 4))
+    a, b = ws[0].engine.state(), ws[1].engine.state()
+    assert a["age"][0] == b["age"][0]
+    t2 = b["theta"][0]
+    terms = -0.5 * np.log(2 * np.pi) - np.log(s2) - 0.5 * ((z2 - plane(t2, X2)) / s2) ** 2
+    assert abs(b["logpost"][0] - terms.sum()) <= REL * np.abs(terms).sum()
+    # a Poisson rate over two variables with the closure likelihood of the README
+    lam = np.exp(0.5 + 0.4 * X[:, 0] + 0.3 * X[:, 1])
+    k = rng.poisson(lam).astype(float)
+    wp = mhx.walker_create(
+        function=mhx.models.lisp("(lambda (x &key u v w &allow-other-keys) (exp (+ u (* v (elt x 0)) (* w (elt x 1)))))"),
+        data=[X, k], params=[":u", 0.45, ":v", 0.42, ":w", 0.28],
+        log_liklihood=mhx.create_log_liklihood_function(
+            "(lambda (y model error) (declare (ignore error)) (- (* y (log model)) model))"), n_chains=2, seed=1)
+    m = np.exp(0.45 + 0.42 * X[:, 0] + 0.28 * X[:, 1])
+    terms = k * np.log(m) - m
+    assert abs(wp.last_step().prob - terms.sum()) <= REL * np.abs(terms).sum()
+    # refused: a function that reads x1 on a dataset of one column; the cutoff likelihood with two
+    e = mhx.Engine(1, 2, 1)
+    e.set_function_expr(0, "a + b*xcol1", ["a", "b"], [0, 1])
+    e.set_dataset(0, X[:, 0], z, sig)
+    with pytest.raises(mhx.MhxError, match="one column"):
+        e.init_chains(np.array([0.0, 1.0]))
+    with pytest.raises(mhx.MhxError, match="cutoff"):
+        e.set_dataset(0, X, z, sig, likelihood=mhx.capi.LIK_NORMAL_CUTOFF)
+    e.close()
