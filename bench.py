@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_SIMD, CLOCK_HZ, CYCLES_PER_F64_INSTR = 1024, 2.4e9, 4
 FP64_VALU_PEAK_TFLOPS = N_SIMD * CLOCK_HZ / CYCLES_PER_F64_INSTR * 128 / 1e12
 FP64_ISSUE_PEAK_G = N_SIMD * CLOCK_HZ / CYCLES_PER_F64_INSTR / 1e9  # G wave-instructions / s
-ROUND_TAG = "r03"  # profiles/<tag>_<workload>_s<steps>_w<warmup>_summary.json
+ROUND_TAG = "r04"  # profiles/<tag>_<workload>_s<steps>_w<warmup>_summary.json
 
 
 def synth_workload(name, rng_key=0x5EED0001):
@@ -625,8 +625,8 @@ def main():
         pw.start(th0, n_adapt, l0)
         for _ in range(w_n):
             pw.advance(w_per)
-        n_disp += pw.timing(reset=True)[0]["launches"]
-        p0 = pw.steps()
+        pw_warm = pw.timing(reset=True)[0]["launches"]   # (its kernel is compiled at run time:
+        p0 = pw.steps()                                   # mhx_user_adaptive, counted on its own)
         sync()
         tp0 = time.perf_counter()
         for _ in range(n_launch):
@@ -640,9 +640,9 @@ def main():
                     "jittered window, the first step again: the recurrence window by window (FnDesc::tgh), "
                     "the direct form only in the junction and jittered windows",
             "kernel_ms_per_launch": pk["avg_ms"],
-            "dispatches": [n_disp, n_disp + pk["launches"]],
+            "kernel": "mhx_user_adaptive @ " + pw.kernel_name(),
+            "dispatches": [pw_warm, pw_warm + pk["launches"]],   # among mhx_user_adaptive's
             "ratio_to_value": out["value"] / out["value_piecewise"]}
-        n_disp += pk["launches"]
         pw.close()
     if rank == 0 and not per_rank and n_gpus == 1 and not args.no_cpu:
         ncpu, cinfo = effective_cores()

@@ -43,6 +43,12 @@ a list of them, one per function; columns may be lists or vectors."
     (when (and depth (= depth 2))       ; a single dataset: wrap it
       (setf data (list data)
             depth 3))
+    ;; one dataset whose x elements are vectors - "multiple or linked independent variables",
+    ;; mcmc-fitting.lisp:1136-1137: ((#(a1 b1) #(a2 b2) ...) (y1 y2 ...)) for ONE function
+    (when (and depth (= depth 3) (= number-of-functions 1) (= (length data) 2)
+               (every #'realp (coerce (second data) 'list)))
+      (setf data (list data)
+            depth 4))
     (unless (and depth (>= depth 3))
       (error "walker-create: :data must be (x-column y-column) or a list of such datasets"))
     (unless (= (length data) number-of-functions)
@@ -108,9 +114,9 @@ structure is taken as is; anything else broadcasts its first element."
                         :operation 'walker-take-step :operands (list :chain (+ first c))))))))
 
 ;;; ------------------------------------------------------------------ walker-create
-(defun %define-problem (walker set-function set-function-expr set-dataset set-bounds
-                        set-prior-expr set-likelihood-expr)
-  "walker-create's per-function work (M:1138-1147), through the six setters of one engine or of
+(defun %define-problem (walker set-function set-function-expr set-dataset set-dataset-cols
+                        set-bounds set-prior-expr set-likelihood-expr)
+  "walker-create's per-function work (M:1138-1147), through the seven setters of one engine or of
 a group (each takes the function index k first and applies CHECK itself)."
   (let* ((keys (walker-param-keys walker)) (d (length keys)))
     (loop for fn in (walker-function walker)
@@ -137,11 +143,22 @@ a group (each takes the function index k first and applies CHECK itself)."
                      (funcall set-function k (model-id fn) cshape (length shape) cidx
                               (length idx))))
                (cffi:with-foreign-objects ((cx :double (max 1 n)) (cy :double (max 1 n))
-                                           (cs :double (max 1 n)))
-                 (fill-doubles cx (first ds))
+                                           (cs :double (max 1 n)) (cx1 :double (max 1 n))
+                                           (cols :pointer 2))
                  (fill-doubles cy (second ds))
                  (fill-doubles cs sg)
-                 (funcall set-dataset k cx cy cs n (likelihood-id lik)))
+                 (if (and (plusp n) (typep (elt (first ds) 0) 'sequence))
+                     ;; a vector-valued x (mcmc-fitting.lisp:1136-1137): its two components as
+                     ;; columns, (elt x 0) -> xcol0, (elt x 1) -> xcol1 (expr.lisp)
+                     (progn
+                       (fill-doubles cx (mapcar (lambda (v) (elt v 0)) (first ds)))
+                       (fill-doubles cx1 (mapcar (lambda (v) (elt v 1)) (first ds)))
+                       (setf (cffi:mem-aref cols :pointer 0) cx
+                             (cffi:mem-aref cols :pointer 1) cx1)
+                       (funcall set-dataset-cols k cols 2 cy cs n (likelihood-id lik)))
+                     (progn
+                       (fill-doubles cx (first ds))
+                       (funcall set-dataset k cx cy cs n (likelihood-id lik)))))
                (when (likelihood-spec-p lik)
                  (funcall set-likelihood-expr k (likelihood-spec-expr lik)))
                (let ((bounds (cond ((null pri) nil)
@@ -228,6 +245,7 @@ the adaptive proposal covariance over all chains (one RCCL all-reduce per 200 st
                 (lambda (k &rest a) (with-c-call (check (apply #'%mhx-group-set-function g k a))))
                 (lambda (k &rest a) (with-c-call (check (apply #'%mhx-group-set-function-expr g k a))))
                 (lambda (k &rest a) (with-c-call (check (apply #'%mhx-group-set-dataset g k a))))
+                (lambda (k &rest a) (with-c-call (check (apply #'%mhx-group-set-dataset-cols g k a))))
                 (lambda (k &rest a) (with-c-call (check (apply #'%mhx-group-set-bounds g k a))))
                 (lambda (k &rest a) (with-c-call (check (apply #'%mhx-group-set-prior-expr g k a))))
                 (lambda (k &rest a) (with-c-call (check (apply #'%mhx-group-set-likelihood-expr g k a)))))
@@ -236,6 +254,7 @@ the adaptive proposal covariance over all chains (one RCCL all-reduce per 200 st
                 (lambda (k &rest a) (with-c-call (check (apply #'%mhx-set-function e k a))))
                 (lambda (k &rest a) (with-c-call (check (apply #'%mhx-set-function-expr e k a))))
                 (lambda (k &rest a) (with-c-call (check (apply #'%mhx-set-dataset e k a))))
+                (lambda (k &rest a) (with-c-call (check (apply #'%mhx-set-dataset-cols e k a))))
                 (lambda (k &rest a) (with-c-call (check (apply #'%mhx-set-bounds e k a))))
                 (lambda (k &rest a) (with-c-call (check (apply #'%mhx-set-prior-expr e k a))))
                 (lambda (k &rest a) (with-c-call (check (apply #'%mhx-set-likelihood-expr e k a))))))

@@ -4,7 +4,7 @@
 # <name> = <round>_<workload>_s<steps>_w<warmup> (what bench.py looks for under profiles/).
 # Usage: tools/run_profile.sh <round tag> <workload> <steps> <warmup> [more bench args...]
 set -e
-TAG=${1:-r03}; WL=${2:-c2}; ST=${3:-200}; WU=${4:-200}; shift 4 || true
+TAG=${1:-r04}; WL=${2:-c2}; ST=${3:-200}; WU=${4:-200}; shift 4 || true
 NAME=${TAG}_${WL}_s${ST}_w${WU}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT/gpurun_out/prof_$NAME
@@ -34,6 +34,10 @@ print("$NAME [%s]: timed region %.3f ms (dispatches %s of %s), vgpr %s scratch %
          t.get("vgpr"), t.get("scratch"), ipp,
          p.get("SQ_INSTS_VALU", 0) * 4 / (1024 * 2.4e9 * dur) if dur else 0,
          p.get("SQ_INSTS_SALU", 0) / max(p.get("SQ_INSTS_VALU", 1), 1), b.get("value", 0)))
+pl, pp = d.get("piecewise_launch"), d.get("pmc_piecewise_launch", {})
+if pl:
+    print("  piecewise grids: %.3f ms, %.2f VALU instr/point, value_piecewise %.4g"
+          % (pl["duration_ns"] * 1e-6, pp.get("SQ_INSTS_VALU", 0) * 64.0 / pts, b.get("value_piecewise", 0)))
 dl, pd = d.get("direct_launch"), d.get("pmc_direct_launch", {})
 if dl:
     print("  direct form: %.3f ms, %.2f VALU instr/point, value_direct_form %.4g"
