@@ -212,3 +212,90 @@ def test_peak_closures_are_recognised_below_the_abi(sx):
     m = M.lisp("(lambda (x &key bg a mu w &allow-other-keys) (+ bg (* a (exp (- (expt (/ (- x mu) w) 2))))))")
     assert m.model_id == lisp_mcmc_amd.capi.MODEL_EXPR and not m.as_written   # libmhx decides
     assert M.lisp("(lambda (x &key m b &allow-other-keys) (+ b (* m x)))", as_written=True).as_written
+
+
+def test_recogniser_fuzz_what_it_accepts_is_what_the_model_computes():
+    """mhx_expr_classify over a few thousand generated C-syntax expressions: peak shapes in many
+    spellings and orders, near-misses, and noise.  Whatever it classifies as an enumerated model
+    must BE that model: the text evaluated as Python arithmetic at random x and parameters equals
+    the model's formula (include/mhx.h) with the keys in the order the classifier returned; and
+    nothing makes it crash or return anything but OK / EINVAL."""
+    import ctypes as C
+    import math
+    import lisp_mcmc_amd
+    import problems as pb
+    lib = lisp_mcmc_amd.capi.lib()
+    rng = np.random.default_rng(2024)
+
+    def classify(cexpr, names):
+        arr = (C.c_char_p * max(len(names), 1))(*[n.encode() for n in names])
+        model, n = C.c_int32(-9), C.c_int32(0)
+        shape, order = (C.c_int32 * 2)(), (C.c_int32 * max(len(names), 1))()
+        rc = lib.mhx_expr_classify(cexpr.encode(), arr, len(names), C.byref(model), shape, order, C.byref(n))
+        assert rc in (0, lisp_mcmc_amd.capi.EINVAL), (rc, cexpr)
+        return rc, model.value, (shape[0], shape[1]), [names[order[j]] for j in range(n.value)]
+
+    def u_of(mu, w):
+        return rng.choice(["((x - %s) / %s)", "((x-%s)/%s)"]) % (mu, w)
+
+    def sq(u):
+        return rng.choice(["ipow(%s, 2)" % u, "pow(%s, 2.0)" % u, "(%s * %s)" % (u, u), "ipow(%s, 2.0)" % u])
+
+    def gauss(a, mu, w):
+        s = sq(u_of(mu, w))
+        neg = rng.choice(["(-%s)" % s, "(-1.0 * %s)" % s, "(%s * -1)" % s])
+        return rng.choice(["(%s * exp(%s))" % (a, neg), "(exp(%s) * %s)" % (neg, a)])
+
+    def lorentz(a, mu, w):
+        s = sq(u_of(mu, w))
+        d = rng.choice(["(1.0 + %s)" % s, "(%s + 1)" % s])
+        return rng.choice(["(%s / %s)" % (a, d), "(%s * (1.0 / %s))" % (a, d)])
+
+    def bgterm(c, deg):
+        if deg == 0:
+            return c
+        xs = rng.choice([" * ".join(["x"] * deg), "ipow(x, %d)" % deg]) if deg > 1 else "x"
+        return rng.choice(["(%s * %s)" % (c, xs), "(%s * %s)" % (xs, c)])
+
+    env = {"exp": math.exp, "pow": math.pow, "ipow": lambda b, p: b ** int(p), "sqrt": math.sqrt,
+           "log": math.log, "sin": math.sin, "cos": math.cos}
+    hits = misses = bad = 0
+    for trial in range(3000):
+        nbg, npk = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        lor = bool(rng.integers(0, 2))
+        names = ["c%d" % i for i in range(nbg)] + [k % i for i in range(npk) for k in ("a%d", "m%d", "s%d")]
+        terms = [bgterm("c%d" % i, i) for i in range(nbg)]
+        terms += [(lorentz if lor else gauss)("a%d" % i, "m%d" % i, "s%d" % i) for i in range(npk)]
+        if not terms:
+            continue
+        rng.shuffle(terms)
+        mut = rng.integers(0, 10)
+        if mut == 0 and npk:                         # a near-miss: another exponent
+            terms[0] = terms[0].replace(", 2", ", 3", 1)
+        elif mut == 1:                               # a key twice
+            terms.append(names[0])
+        elif mut == 2:                               # noise
+            terms.append(rng.choice(["sin(x)", "2.5", "(x > 0.5 ? 1.0 : 0.0)", "c0 c1", "((", "exp(x"]))
+        elif mut == 3 and nbg >= 2:                  # a gap in the background's degrees
+            terms = [t for t in terms if t != bgterm("c1", 1) and "c1" not in t]
+            names = [n for n in names if n != "c1"]
+        text = " + ".join(terms)
+        if rng.integers(0, 2):
+            text = "(" + text + ")"
+        rc, model, shape, order = classify(text, list(rng.permutation(names)))
+        if rc != 0:
+            bad += 1
+            continue
+        if model == lisp_mcmc_amd.capi.MODEL_EXPR:
+            misses += 1
+            continue
+        hits += 1
+        vals = {n: float(rng.uniform(0.3, 2.0)) for n in names}
+        p = np.array([vals[k] for k in order])
+        for xv in rng.uniform(-1, 2, 4):
+            want = eval(text.replace("?", " if ").replace(":", " else "), dict(env, x=float(xv), **vals)) \
+                if "?" not in text else None
+            mid = {0: pb.POLY, 1: pb.GAUSS, 2: pb.LORENTZ}[model]
+            got = float(pb.model_eval_np(mid, shape if model else (), p, np.array([xv]))[0])
+            assert want is not None and abs(got - want) <= 1e-12 * max(1.0, abs(want)), (text, order, xv, got, want)
+    assert hits > 800 and misses > 300 and bad > 50, (hits, misses, bad)
