@@ -1258,15 +1258,25 @@ __device__ __forceinline__ void persist_publish(const ChainState& S, int64_t c, 
 // split mode: the same value from the partial sums the sweep launch left in S.split_part
 // PERSIST (k_persist's master wave): the partial sums arrive as {sum, generation} pairs in
 // S.persist_part while this waits - every slot's pair is read until it carries generation `gen`;
-// a slot that never does (patience) makes the sum a NaN, which freezes the chain.
+// a slot that never does (patience) is reported through *lost: the caller takes the iteration
+// back and ends the launch.
 template <class Spec, bool PERSIST = false>
 __device__ __forceinline__ double split_logpost(const ProblemDesc& P, const ChainState& S,
                                                 int64_t c, bool active, GroupLds& lds, int w,
                                                 double* ll_out, double* lp_out,
-                                                unsigned long long gen = 0) {
+                                                unsigned long long gen = 0, bool* lost_out = nullptr) {
   double ll = 0.0, lp = 0.0;
   const double* th = lds.prop[w];
   const int l = lane_id();
+  if constexpr (PERSIST) {
+    // the priors need the proposal, not the sums: formed while the sums are on their way (their
+    // reads of the bounds are a memory round trip on every iteration's critical path otherwise)
+    for (int k = 0; k < P.K; ++k) {
+      const FnDesc& f = P.fn[k];
+      const double q = Spec::logprior(f, th, logprior_fn(f, th));
+      lp = k == 0 ? q : lp + q;
+    }
+  }
   for (int k = 0; k < P.K; ++k) {
     const FnDesc& f = P.fn[k];
     const double* part = S.split_part + ((active ? c : 0) * P.K + k) * S.split_slots;
@@ -1295,13 +1305,15 @@ __device__ __forceinline__ double split_logpost(const ProblemDesc& P, const Chai
         }
         if (sl < S.split_slots) a = a + v;  // slot order per lane, as below
       }
-      if (lost) a = __builtin_nan("");
+      if (lost && lost_out) *lost_out = true;
     } else
     for (int s = l; s < S.split_slots; s += kWave) a = a + part[s];  // slot order, fixed
     const double v = finish_by_lik(f, wave_sum(a));
     ll = k == 0 ? v : ll + v;
-    const double q = Spec::logprior(f, th, logprior_fn(f, th));
-    lp = k == 0 ? q : lp + q;
+    if constexpr (!PERSIST) {
+      const double q = Spec::logprior(f, th, logprior_fn(f, th));
+      lp = k == 0 ? q : lp + q;
+    }
   }
   *ll_out = ll;
   *lp_out = lp;
@@ -1684,7 +1696,13 @@ __device__ __forceinline__ void chain_store(const ChainState& S, int64_t c, int 
 
 // get-covariant-sample M:679-700: lane i forms sum_j L_ij z_j from 0d0 (multiply, then add),
 // then adds theta_i.  z_j sits in lane j of zv.
+// (propose_lz: the product alone - the persistent master forms the next proposal's while it waits
+// for this one's sums, and adds theta when the accept decision has said which theta)
+__device__ __forceinline__ double propose_lz(const double* L, int d, double zv);
 __device__ __forceinline__ double propose(const double* L, int d, double zv, double th) {
+  return propose_lz(L, d, zv) + th;
+}
+__device__ __forceinline__ double propose_lz(const double* L, int d, double zv) {
   const int l = lane_id();
   double mini = 0.0;
   // eight elements of the lane's row at a time, all loads before the first use: one round trip
@@ -1701,7 +1719,7 @@ __device__ __forceinline__ double propose(const double* L, int d, double zv, dou
       }
     }
   }
-  return mini + th;
+  return mini;
 }
 
 // walker-modify :add-step M:549-555 on the ring.  th: the step's position (lane j: theta_j),
@@ -1851,8 +1869,9 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
   // PERSIST: the next iteration's random numbers are drawn while this one's partial sums are on
   // their way (the draw counter does not depend on the accept decision), and the proposal factor
   // waits in LDS (the master's workgroup stages no tiles), re-read after every change
-  double rv_pre = 0.0, lg_pre = 0.0;
-  bool have_pre = false, l_stale = true, stop_sent = false;
+  double rv_pre = 0.0, lg_pre = 0.0, lz_pre = 0.0;
+  bool have_pre = false, have_lz = false, l_stale = true, stop_sent = false;
+  (void)lz_pre; (void)have_lz;
   (void)stop_sent;
   // (one copy per master wave of the workgroup where they all fit, else the factor stays in HBM)
   const bool l_in_lds = PERSIST && (group < 0 ? 1 : kWavesPerGroup) * d * d * sizeof(double) <= sizeof(lds.tiles);
@@ -1971,8 +1990,10 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
           for (int e = l; e < d * d; e += kWave) l_lds[e] = Lc[e];
           __builtin_amdgcn_wave_barrier();
           l_stale = false;
+          have_lz = false;  // (formed with the old factor)
         }
-        thp = propose(l_lds, d, rv, cur_in_lds ? (l < d ? lds.cur[w][l] : 0.0) : chain_theta(S, c, d));
+        const double lz = have_lz ? lz_pre : propose_lz(l_lds, d, rv);
+        thp = lz + (cur_in_lds ? (l < d ? lds.cur[w][l] : 0.0) : chain_theta(S, c, d));
       } else {
         thp = propose(Lc, d, rv, cur_in_lds ? (l < d ? lds.cur[w][l] : 0.0) : chain_theta(S, c, d));
       }
@@ -1994,6 +2015,10 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
         persist_publish(S, c, d, thp, (unsigned long long)(it + 1));
         rv_pre = rng_lane_value(S.seed, gchain, r.draw, d, &lg_pre);  // (the next iteration's)
         have_pre = true;
+        if (l_in_lds && !l_stale) {  // ... and its L z (the factor changes only at adaptation ticks)
+          lz_pre = propose_lz(l_lds, d, rv_pre);
+          have_lz = true;
+        }
       }
     }
     }  // !resumed
@@ -2012,10 +2037,19 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
 #ifndef MHX_NO_PARK  // (build knob for A/B measurements)
     if constexpr (!SPLIT) chain_park(slot, r, u, t_next);
 #endif
-    if constexpr (PERSIST)
+    if constexpr (PERSIST) {
+      bool lost = false;
       prob1 = split_logpost<Spec, true>(P, S, c, running, lds, w, &ll, &lp,
-                                        (unsigned long long)(it + 1));
-    else if constexpr (SPLIT)
+                                        (unsigned long long)(it + 1), &lost);
+      if (__builtin_amdgcn_readfirstlane((int)lost)) {
+        // the sweep workgroups did not answer (not all of them were on the GPU): nothing was
+        // judged - the proposal is taken back (the next launch draws it again) and this chain's
+        // part of the launch ends; the host hears about it (persist_error)
+        r.draw--;
+        if (l == 0) __hip_atomic_store(S.persist_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    } else if constexpr (SPLIT)
       prob1 = split_logpost<Spec>(P, S, c, running, lds, w, &ll, &lp);
     else
       prob1 = group_logpost<Spec>(P, running, lds, w, &ll, &lp);
@@ -2289,6 +2323,7 @@ __device__ __forceinline__ void k_persist_body(const ProblemDesc* __restrict__ P
     valid = in_range && mapped >= 0;
     c = valid ? mapped : 0;
   }
+  if (blockIdx.x != 0 && P.test_lose_sweepers != 0) return;  // (tests: the masters are left alone)
   if (blockIdx.x == 0) {
     if (!TS && w != 0) return;  // (s_barrier counts the waves still alive)
     k_adaptive_body<Spec, true, true>(Pp, S, R, max_iters, plain, 1, TS ? (int64_t)blockIdx.y : -1);
@@ -2327,9 +2362,16 @@ __device__ __forceinline__ void k_persist_body(const ProblemDesc* __restrict__ P
     lds_begin(lds);
     const int slice = (int)blockIdx.x - 1;
     bool alive = valid;
+#ifdef MHX_PERSIST_TIMING  // (measurement build: where a sweep workgroup's round goes)
+    unsigned long long t_poll = 0, t_vote = 0, t_sweep = 0, t0 = __builtin_readcyclecounter(), rounds = 0;
+#define MHX_PT(acc) do { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - t0; t0 = n_; } while (0)
+#else
+#define MHX_PT(acc) do { } while (0)
+#endif
     for (unsigned long long round = 0;; ++round) {
       unsigned long long q = 0;
       if (alive) alive = persist_poll(S, c, d, round, &q);
+      MHX_PT(t_poll);
       const bool active = alive;
       // anybody of the group still walking?  (a flag and ONE barrier, as in k_adaptive_body)
       const int vp = (int)(round % 3);
@@ -2339,6 +2381,24 @@ __device__ __forceinline__ void k_persist_body(const ProblemDesc* __restrict__ P
       __syncthreads();
       const int any = __builtin_amdgcn_readfirstlane(*(volatile int*)&lds.vote[vp]);
       if (threadIdx.x == 0) lds.vote[(vp + 2) % 3] = 0;
+      MHX_PT(t_vote);
+#ifdef MHX_PERSIST_TIMING
+      if (!any && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0) {
+        printf("sweep wg (1,0) wave 0: rounds %llu, cycles per round: poll %llu vote %llu sweep %llu\n", rounds,
+               t_poll / (rounds + 1), t_vote / (rounds + 1), t_sweep / (rounds + 1));
+#ifdef MHX_X_TIMING
+        printf("   inside the sweep (MHX_TIM phases 0-7, cycles per round): %llu %llu %llu %llu %llu %llu %llu %llu\n",
+               lds.tim[0][0] / (rounds + 1), lds.tim[0][1] / (rounds + 1), lds.tim[0][2] / (rounds + 1),
+               lds.tim[0][3] / (rounds + 1), lds.tim[0][4] / (rounds + 1), lds.tim[0][5] / (rounds + 1),
+               lds.tim[0][6] / (rounds + 1), lds.tim[0][7] / (rounds + 1));
+#endif
+      }
+      ++rounds;
+#ifdef MHX_X_TIMING
+      if (round == 0 && l == 0) { for (int k = 0; k < 8; ++k) lds.tim[w][k] = 0; }
+      if (l == 0) lds.tlast[w] = __builtin_readcyclecounter();
+#endif
+#endif
       if (!any) return;
       const double* th = lds.prop[w];
       for (int k = 0; k < P.K; ++k) {
@@ -2350,6 +2410,8 @@ __device__ __forceinline__ void k_persist_body(const ProblemDesc* __restrict__ P
           persist_store_pair((char*)S.persist_part + (((size_t)c * P.K + k) * S.split_slots + slice) * 16,
                              raw, round + 1);
       }
+      MHX_TIM(lds, 6);
+      MHX_PT(t_sweep);
     }
   }
 }

@@ -65,7 +65,8 @@ struct FnDesc {
 struct ProblemDesc {
   int32_t d, K;
   int32_t no_deal;  // 1: wave w judges the proposal of its own chain (MHX_NO_DEAL=1; group_logpost)
-  int32_t pad_;
+  int32_t test_lose_sweepers;  // 1 (test library only): k_persist's sweep workgroups leave at once,
+                               // as if they had never got onto the GPU
   FnDesc fn[MHX_MAX_FUNCTIONS];
 };
 
@@ -126,6 +127,10 @@ struct ChainState {
   // instruction that goes to the level every XCD sees (sc1): who finds the tag finds the data.
   unsigned long long* persist_msg;
   void* persist_part;
+  // set by a master whose sweep workgroups did not answer within its patience (they were not all
+  // on the GPU - another kernel held it): the iteration is taken back, the launch ends, the host
+  // reports it (MHX_EDEVICE) and goes back to the two-launch form
+  int32_t* persist_error;
 };
 
 struct RunDesc {

@@ -443,3 +443,53 @@ def test_config5_in_its_eight_engine_form_on_one_gpu(tmp_path):
     assert [c.split()[1] for c in calls[i + 1:i + 9]] == ["rank=%d" % r for r in range(8)]
     assert calls[i + 9] == "GroupEnd depth=0 pending=8" and calls[i + 10] == "flush clique_of=8 count=73 rc=0"
     assert sum(c.startswith("CommDestroy") for c in calls) == 8
+
+
+def test_persistent_launch_whose_sweepers_never_come_is_taken_back(tmp_path):
+    """k_persist counts on all its workgroups being on the GPU at once.  When they are not
+    (another kernel holds the GPU for longer than a master's patience) the master takes its
+    proposal back, the launch ends, mhx_adaptive_advance answers MHX_EDEVICE with no chain
+    touched, and the engine goes back to two launches per iteration - after a new begin the walk is
+    the one a two-launch engine walks.  The test library's MHX_TEST_LOSE_SWEEPERS=1 makes the
+    sweep workgroups leave at once."""
+    env = dict(os.environ, MHX_LIBRARY=HOOKS, MHX_TEST_LOSE_SWEEPERS="1")
+    for k in ("MHX_SPLIT", "MHX_TSPLIT", "MHX_NO_PERSIST"):
+        env.pop(k, None)
+    body = PRELUDE + textwrap.dedent("""
+        s = pb.two_peak(n=30000, seed=3)
+        th0 = pb.perturbed(s.theta_star, 2, 0.01, seed=2)
+        e = s.engine(mhx, 2, seed=9)
+        e.init_chains(th0)
+        assert "persistent split x" in e.kernel_name(), e.kernel_name()
+        before = e.state()
+        e.adaptive_begin(900, 10.0, 1)
+        try:
+            e.adaptive_advance(50)
+            raise SystemExit("the launch should have failed")
+        except mhx.MhxError as ex:
+            assert ex.code == mhx.capi.EDEVICE and "persistent launch" in str(ex), ex
+        after = e.state()
+        for k in ("theta", "logpost", "age", "length"):
+            assert np.array_equal(before[k], after[k]), k      # no chain was touched
+        assert (e.chain_status()[0] == mhx.capi.CHAIN_RUNNING).all()
+        try:
+            e.adaptive_advance(10)
+            raise SystemExit("the run should be over")
+        except mhx.MhxError as ex:
+            assert ex.code == mhx.capi.ESTATE
+        assert "persistent" not in e.kernel_name() and "split x" in e.kernel_name(), e.kernel_name()
+        e.adaptive_begin(900, 10.0, 1)
+        e.adaptive_advance(1 << 40)
+        os.environ["MHX_NO_PERSIST"] = "1"
+        ref = s.engine(mhx, 2, seed=9)
+        ref.init_chains(th0)
+        ref.adaptive_begin(900, 10.0, 1)
+        ref.adaptive_advance(1 << 40)
+        a, b = e.state(), ref.state()
+        for k in ("theta", "logpost", "age", "length"):
+            assert np.array_equal(a[k], b[k]), k
+        print("ok", flush=True)
+    """)
+    out = subprocess.run([sys.executable, "-c", body], capture_output=True, text=True, env=env, timeout=600)
+    assert "ok" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+    assert out.returncode == 0

@@ -79,5 +79,46 @@ def main():
             sys.stdout.flush()
 
 
+def bindings():
+    """Round 4: the abort reproduces - old flags, order rccl,rtc,torch: `double free or corruption
+    (!prev)` after the work is done; RTLD_LOCAL, same order: exit status 0.  This pass runs that
+    one configuration under LD_DEBUG=bindings and prints which libraries had symbols of theirs
+    bound INTO the librccl that libmhx opened (what RTLD_GLOBAL makes possible and RTLD_LOCAL
+    does not): the mechanism, not only the correlation."""
+    import collections
+    import glob
+    import re
+    import tempfile
+    out = tempfile.mkdtemp(prefix="mhx_ldd_")
+    for glob_flag in ("1", "0"):
+        base = os.path.join(out, "b%s" % glob_flag)
+        env = dict(os.environ, ORDER="rccl,rtc,torch", MHX_RCCL_DLOPEN_GLOBAL=glob_flag, MHX_SPLIT="0",
+                   MHX_LIBRARY=os.path.join(ROOT, "tests", "hooks", "libmhx_hooks.so"),
+                   LD_DEBUG="bindings", LD_DEBUG_OUTPUT=base)
+        try:
+            r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=600)
+            status = r.returncode
+        except subprocess.TimeoutExpired:
+            status = "timeout"
+        into = collections.Counter()
+        syms = collections.Counter()
+        pat = re.compile(r"binding file (\S+) \[\d+\] to (\S+) \[\d+\]: normal symbol `([^']+)'")
+        for f in glob.glob(base + ".*"):
+            for line in open(f, errors="replace"):
+                m = pat.search(line)
+                if m and "librccl" in m.group(2) and "librccl" not in m.group(1) and "libmhx" not in m.group(1):
+                    into[os.path.basename(m.group(1))] += 1
+                    syms[m.group(3)] += 1
+        print("==== RTLD_%s order=rccl,rtc,torch under LD_DEBUG=bindings -> exit status %s"
+              % ("GLOBAL|NODELETE" if glob_flag == "1" else "LOCAL", status))
+        print("   symbols of OTHER libraries bound into libmhx's librccl: %d, from %s"
+              % (sum(into.values()), dict(into.most_common(8))))
+        print("   the most frequent: %s" % [s for s, _ in syms.most_common(12)])
+        sys.stdout.flush()
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--bindings":
+        bindings()
+    else:
+        main()
