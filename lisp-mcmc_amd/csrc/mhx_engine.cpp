@@ -332,11 +332,29 @@ std::string builtin_model_type(const FnDesc& f) {
   }
 }
 
+// May this engine use the persistent kernels at all (MHX_NO_PERSIST=1: never; persist_off: a
+// launch of theirs once lost its sweep workgroups; their handshake blocks carry 60 parameters)
+static bool persist_allowed(const mhx_engine* e) {
+  const char* np_ = getenv("MHX_NO_PERSIST");
+  return !e->persist_off && !(np_ && atoi(np_) != 0) && e->P.d <= 60;
+}
+// MHX_PERSIST_TS: 1 = the tile-sliced persistent form wherever two slices of it fit, 0 = never,
+// unset (-1) = where it fits with at least three quarters of the default slicing
+static int persist_ts_wanted() {
+  const char* s = getenv("MHX_PERSIST_TS");
+  return s ? (atoi(s) != 0 ? 1 : 0) : -1;
+}
+int64_t persist_capacity(const mhx_engine* e, bool ts);
+
 // Split mode (mhx_kernels.hpp): how many workgroups share one chain's likelihood sums, or 0 for
 // the batch kernels.  Worth it when the batch launch would leave most CUs without a workgroup
 // and every (slice, wave) slot still gets at least 512 points of the longest dataset.
 // MHX_SPLIT=0 switches it off, MHX_SPLIT=<n> forces n slices.
-int choose_split(const mhx_engine* e, const Family& fam, bool capable) {
+// cap_pc > 0: the per-chain persistent form (k_persist: one launch per portion of iterations) is
+// allowed and the GPU holds that many of its workgroups at once - where C (1 + slices) of them
+// fit, split mode costs 7.6 us per iteration instead of the two launches' 14 and pays off on
+// shorter datasets (4096 points: 13.4 us in the batch kernel).
+int choose_split(const mhx_engine* e, const Family& fam, bool capable, int64_t cap_pc) {
   if (!capable || e->cfg.adapt_mode == MHX_ADAPT_POOLED) return 0;
   int64_t longest = 0;
   for (int k = 0; k < e->P.K; ++k) longest = std::max<int64_t>(longest, e->P.fn[k].n);
@@ -368,8 +386,12 @@ int choose_split(const mhx_engine* e, const Family& fam, bool capable) {
   const int64_t batch_groups = (C + W - 1) / W;
   if (batch_groups >= (heavy ? 256 : 128)) return 0;
   // two launches cost about 14 us per iteration: the fused batch kernel is quicker than that up
-  // to roughly a dozen 1024-point tiles
-  if (by_data < 4) return 0;
+  // to roughly a dozen 1024-point tiles; one persistent launch is quicker from one slice's worth
+  // of points on (the batch kernel: 13.4 us on 4096 points)
+  if (by_data < 4) {
+    if (by_data >= 1 && !heavy && C * (1 + by_data) <= cap_pc) return (int)by_data;
+    return 0;
+  }
   // (cheap points: beyond 8 slices the partial sums and the extra blocks cost more than they
   // bring once there are 32 chains and more - 64 chains: x16 2.2e6, x8 2.4e6, x4 2.4e6)
   const int64_t want = heavy ? std::max<int64_t>(4, 2048 / C)
@@ -384,7 +406,15 @@ int choose_split(const mhx_engine* e, const Family& fam, bool capable) {
 // about two workgroups per CU in the sweep launch.  MHX_TSPLIT=0 switches it off (the per-chain
 // split mode or the batch kernels then), MHX_TSPLIT=<n> asks for n slices; MHX_SPLIT=0 means the
 // batch kernels here too, MHX_SPLIT=<n> alone the per-chain split mode.
-int choose_tsplit(const mhx_engine* e, const Family& fam, bool capable) {
+// cap_pc, cap_ts > 0: the persistent forms are allowed (workgroups of k_persist / k_persist_ts the
+// GPU holds at once).  One persistent launch costs about 10.3 us per iteration where the two
+// launches cost 20 (measured round 4, two-peak problem, us per iteration, persistent | default
+// of round 3):  8192 points  32 chains 12.4 | 18.2 (batch kernel)    256: 12.4 | 18.5
+//   20000 points  128: 11.1 | 22.1 (per-chain split)    256: 13.2 | 28.9
+//   50000 points  8: 10.4 | 20.4 (two launches)    128: 11.9 | 23.5
+// so it serves from 4 windows on - unless the per-chain persistent form fits, which is quicker
+// still on short datasets (20000 points, 8 ... 64 chains: 7.7 ... 8.7 us).
+int choose_tsplit(const mhx_engine* e, const Family& fam, bool capable, int64_t cap_pc, int64_t cap_ts) {
   if (!capable || e->cfg.adapt_mode == MHX_ADAPT_POOLED) return 0;
   int64_t longest = 0;
   for (int k = 0; k < e->P.K; ++k) longest = std::max<int64_t>(longest, e->P.fn[k].n);
@@ -410,7 +440,14 @@ int choose_tsplit(const mhx_engine* e, const Family& fam, bool capable) {
       heavy = heavy || fd.lik == MHX_LIK_POISSON || fd.lik == MHX_LIK_EXPR ||
               fd.model == MHX_MODEL_PVOIGT2 || fd.model == MHX_MODEL_EXPR;
     }
-    if (C < W || groups >= 256 || nwin < (heavy ? 4 : 12)) return 0;
+    if (C < W || groups >= 256) return 0;
+    if (nwin < (heavy ? 4 : 12)) {
+      // too short for two launches per iteration: as one persistent launch, or not at all
+      if (nwin < (heavy ? 2 : 4) || groups * (1 + nwin) > cap_ts) return 0;
+      const int pc = choose_split(e, fam, capable, cap_pc);
+      if (pc > 0 && C * (1 + pc) <= cap_pc) return 0;  // (the per-chain persistent form)
+      return (int)nwin;
+    }
     // measured (config 2's problem, chain-steps/s; slices 4 | 8 | 16 | 32 | 49):
     //   64 chains 1.5e6 | 2.1e6 | 2.6e6 | 3.1e6 | 3.1e6     256: 6.0e6 | 7.9e6 | 8.0e6 | 7.0e6 | 6.3e6
     //   1024: 1.47e7 | 1.33e7 | 1.13e7 | 9.2e6 | 8.8e6       (per-chain split mode: 2.4e6, 4.7e6; batch
@@ -475,11 +512,17 @@ const Family& choose_family(const mhx_engine* e) {
 
 // workgroups of the stepping kernels the GPU holds at once, with a tenth in hand: what a
 // persistent launch (k_persist, k_persist_ts) may ask for - its workgroups wait for one another
-int64_t persist_capacity(const mhx_engine* e) {
+// Workgroups of a persistent launch the GPU holds at once: CUs times what the occupancy
+// calculator gives the COMPILED kernel (registers, LDS and waves - an assumed "two per CU" was
+// wrong for a kernel of 132 VGPRs and cost half the speed, see k_persist_ts), less a tenth for
+// whatever else runs on the device.
+int64_t persist_capacity(const mhx_engine* e, bool ts) {
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus <= 0)
     cus = 256;
-  return (int64_t)cus * (e->fam->waves_per_group <= 8 ? 2 : 1) * 9 / 10;
+  const int per_cu = e->spec == SPEC_USER ? rtc_persist_per_cu(*e->user_prog, ts ? 1 : 0)
+                                          : e->fam->persist_per_cu(e->spec, ts ? 1 : 0);
+  return (int64_t)cus * per_cu * 9 / 10;
 }
 
 int finalize_problem(mhx_engine* e) {
@@ -687,8 +730,10 @@ int finalize_problem(mhx_engine* e) {
     }
     HIP_TRY(hipMemcpy(e->dP.p, &e->P, sizeof(ProblemDesc), hipMemcpyHostToDevice));
     std::string err;
-    const bool want_split =
-        choose_split(e, *e->fam, !builtin) > 0 || choose_tsplit(e, *e->fam, !builtin) > 0;
+    // (before the kernels exist their occupancy is not known: the most they could have)
+    const int64_t cap_guess = persist_allowed(e) ? 2 * 256 : 0;
+    const bool want_split = choose_split(e, *e->fam, !builtin, cap_guess) > 0 ||
+                            choose_tsplit(e, *e->fam, !builtin, cap_guess, cap_guess) > 0;
     std::shared_ptr<UserProgram> prog =
         rtc_get(models, priors, builtin, want_split, *e->fam, &err);
     if (prog) {
@@ -708,9 +753,12 @@ int finalize_problem(mhx_engine* e) {
   {
     const bool capable = e->spec == SPEC_USER ? e->user_prog->has_split
                                               : e->fam->split_capable(e->spec);
-    const int ts = choose_tsplit(e, *e->fam, capable);
+    const bool pa = capable && persist_allowed(e);
+    const int64_t cap_pc = pa ? persist_capacity(e, false) : 0;
+    const int64_t cap_ts = pa && persist_ts_wanted() != 0 ? persist_capacity(e, true) : 0;
+    const int ts = choose_tsplit(e, *e->fam, capable, cap_pc, cap_ts);
     e->tsplit = ts > 0;
-    e->split_slices = e->tsplit ? ts : choose_split(e, *e->fam, capable);
+    e->split_slices = e->tsplit ? ts : choose_split(e, *e->fam, capable, cap_pc);
     e->S.split_slots = e->tsplit ? e->split_slices : e->split_slices * e->fam->waves_per_group;
     e->S.split_part = nullptr;
     e->ts_initial = e->tsplit ? ts : 0;
@@ -744,18 +792,27 @@ int finalize_problem(mhx_engine* e) {
       // where the default slicing would not fit the GPU at once (a run's repacking keeps to the
       // same bound: compact_tsplit)
       const int64_t units = e->tsplit ? (e->cfg.n_chains + W - 1) / W : e->cfg.n_chains;
-      const int64_t cap = persist_capacity(e);
+      const int64_t cap = persist_capacity(e, e->tsplit);
       int64_t slices = e->split_slices;
-      if (e->tsplit && getenv("MHX_PERSIST_TS") && atoi(getenv("MHX_PERSIST_TS")) != 0 && !getenv("MHX_TSPLIT"))
-        slices = std::min<int64_t>(slices, cap / units - 1);
-      // (the tile-sliced form is built and bit-identical, but no faster than its two launches -
-      // 64 walkers on 1e5 points 20.5 against 19.9 us per iteration, 256: 31.8 against 31.2, and
-      // slower where the GPU does not hold the default slicing at once (1024: 103 against 69) -
-      // so it waits behind MHX_PERSIST_TS=1; the per-chain form halves a single walker's step)
-      const char* pts = getenv("MHX_PERSIST_TS");
-      const bool want = e->tsplit ? (pts && atoi(pts) != 0) : true;
-      e->persist = want && !e->persist_off && !(np_ && atoi(np_) != 0) && slices >= (e->tsplit ? 2 : 1) &&
-                   units * (1 + slices) <= cap && e->P.d <= 60;
+      // The tile-sliced form runs with fewer slices where the default slicing does not fit the
+      // GPU at once - down to three quarters of it (MHX_PERSIST_TS=1: down to 2; =0: never the
+      // persistent form).  Measured round 4 (two-peak problem, 1e5 points, us per iteration,
+      // persistent | two launches):  8 chains x49 10.1 | 20.0    64: x49 12.2 | 23.0
+      //   128: x27 14.3 | x32 26.5    256: x13 19.6 | x16 33.6    512: x6 31.2 | x8 46.6
+      //   1024: x2 68.9 | x4 71.7;   1e6 points  8: 15.4 | 23.8    64: 34.5 | 45.8
+      //   256: 120 | 121    1024: x2 611 | x4 429 (half the slices: not taken).
+      // (Round 3 had measured the persistent form no faster and left it behind a switch: its
+      // kernel took 132 VGPRs, one workgroup fitted a CU, and the launch ran in two shifts.)
+      const int wanted = persist_ts_wanted();
+      if (e->tsplit && !getenv("MHX_TSPLIT")) {
+        const int64_t fit = std::min<int64_t>(slices, cap / units - 1);
+        const int64_t least = wanted > 0 ? 2 : std::max<int64_t>(2, (3 * slices + 3) / 4);
+        slices = fit >= least ? fit : 0;
+      }
+      const bool want = e->tsplit ? wanted != 0 : true;
+      e->persist = want && persist_allowed(e) && slices >= (e->tsplit ? 2 : 1) &&
+                   units * (1 + slices) <= cap;
+      (void)np_;
       if (e->persist && e->tsplit && slices != e->split_slices) {
         const int rc = build_ts_table(e, (int)slices);
         if (rc != MHX_OK) return rc;
@@ -1045,7 +1102,7 @@ int compact_tsplit(mhx_engine* e, const std::vector<int32_t>& st, int64_t runnin
                       : std::max<int64_t>(e->split_slices,
                                           std::min<int64_t>(std::min<int64_t>(512 / groups, nwin), 512));
   if (e->persist && !forced)  // (every workgroup of a persistent launch on the GPU at once)
-    ts = std::max<int64_t>(2, std::min<int64_t>(ts, persist_capacity(e) / groups - 1));
+    ts = std::max<int64_t>(2, std::min<int64_t>(ts, persist_capacity(e, true) / groups - 1));
   if (ts != e->split_slices) {
     const int rc = build_ts_table(e, (int)ts);
     if (rc != MHX_OK) return rc;

@@ -1219,6 +1219,26 @@ constexpr unsigned long long kPersistStop = 1ull << 31;  // generation half: the
 __device__ __forceinline__ unsigned persist_fold(unsigned long long v) {
   return (unsigned)v ^ (unsigned)(v >> 32) ^ 0x9E3779B9u;
 }
+#ifdef MHX_PERSIST_TIMING  // (measurement build: one record per workgroup, read by the launcher)
+__device__ unsigned long long g_persist_trace[1024][8];
+__device__ __forceinline__ void persist_trace(unsigned long long a, unsigned long long b, unsigned long long c,
+                                              unsigned long long n) {
+  unsigned hw = 0, xcc = 0;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const unsigned i = blockIdx.y * gridDim.x + blockIdx.x;
+  if (i < 1024) {
+    unsigned long long* r = g_persist_trace[i];
+    r[0] = xcc & 15; r[1] = (hw >> 13) & 7; r[2] = (hw >> 8) & 15; r[3] = a; r[4] = b; r[5] = c; r[6] = n;
+    r[7] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+#endif
+#ifdef MHX_PERSIST_NOPRIO  // (A/B knob: tools/debug/persist_prio_ab.sh)
+#define MHX_PERSIST_PRIO(P) do { } while (0)
+#else
+#define MHX_PERSIST_PRIO(P) __builtin_amdgcn_s_setprio(P)
+#endif
 constexpr unsigned kPersistPatience = 1u << 20;   // polls (a memory round trip apart) before giving up
 constexpr int kPersistMaxParams = 60;             // four lines of 15 parameters and a tag
 typedef __attribute__((ext_vector_type(4))) unsigned int persist_u4;
@@ -1284,6 +1304,7 @@ __device__ __forceinline__ double split_logpost(const ProblemDesc& P, const Chai
     if constexpr (PERSIST) {
       const char* pairs = (const char*)S.persist_part + (((active ? c : 0) * P.K + k) * S.split_slots) * 16;
       bool lost = false;
+      MHX_PERSIST_PRIO(0);  // (waiting: see persist_poll)
       for (int s0 = 0; s0 < S.split_slots && active; s0 += kWave) {  // (uniform)
         const int sl = s0 + l;
         double v = 0.0;
@@ -1306,6 +1327,7 @@ __device__ __forceinline__ double split_logpost(const ProblemDesc& P, const Chai
         if (sl < S.split_slots) a = a + v;  // slot order per lane, as below
       }
       if (lost && lost_out) *lost_out = true;
+      MHX_PERSIST_PRIO(3);  // (the controller: the serial part of the round)
     } else
     for (int s = l; s < S.split_slots; s += kWave) a = a + part[s];  // slot order, fixed
     const double v = finish_by_lik(f, wave_sum(a));
@@ -1808,6 +1830,23 @@ __device__ __forceinline__ int64_t floor_mod(int64_t a, int64_t b) {
   const int64_t m = a % b;
   return m < 0 ? m + b : m;
 }
+// The loop index modulo 200, 1000 and 2 sts, carried along instead of divided out: three 64-bit
+// divisions per iteration are nothing beside a sweep of the batch kernels, but a tenth of a
+// microsecond each on the path a persistent kernel's sweep workgroups wait on.
+struct LoopPhases {
+  int m200, m1000;
+  int64_t msts;
+  __device__ __forceinline__ void set(int64_t i, int64_t sts) {
+    m200 = (int)floor_mod(i, 200);
+    m1000 = (int)floor_mod(i, 1000);
+    msts = floor_mod(i, 2 * sts);
+  }
+  __device__ __forceinline__ void step(int64_t sts) {
+    if (++m200 == 200) m200 = 0;
+    if (++m1000 == 1000) m1000 = 0;
+    if (++msts == 2 * sts) msts = 0;
+  }
+};
 
 // The do loop of walker-adaptive-steps-full (M:902-942), up to max_iters iterations for each
 // chain of the workgroup.  plain != 0: walker-many-steps (M:849-853): constant L, T = 1.
@@ -1846,6 +1885,9 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
   ChainRegs r;
   r.status = MHX_CHAIN_DONE;
   if (valid) chain_load(S, c, d, r);
+  LoopPhases ph = {0, 0, 0};
+  if (PERSIST && valid) ph.set(r.loop_i, R.sts);
+  (void)ph;
   const bool cur_in_lds = d <= kCurParams;
   if (valid && cur_in_lds && lane_id() < d) lds.cur[w][lane_id()] = S.theta[c * d + lane_id()];
   double* Lc = S.L + (valid ? c : 0) * d * d;
@@ -1870,6 +1912,11 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
   // their way (the draw counter does not depend on the accept decision), and the proposal factor
   // waits in LDS (the master's workgroup stages no tiles), re-read after every change
   double rv_pre = 0.0, lg_pre = 0.0, lz_pre = 0.0;
+  if constexpr (PERSIST) MHX_PERSIST_PRIO(3);  // (a master's controller: see persist_poll)
+#ifdef MHX_PERSIST_TIMING
+  unsigned long long pt_ctrl = 0, pt_wait = 0, pt_n = 0, pt_last = __builtin_readcyclecounter();
+  const unsigned long long pt_rt0 = __builtin_amdgcn_s_memrealtime(), pt_c0 = pt_last;
+#endif
   bool have_pre = false, have_lz = false, l_stale = true, stop_sent = false;
   (void)lz_pre; (void)have_lz;
   (void)stop_sent;
@@ -1946,7 +1993,14 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     {
       const int vp = (int)(it % 3);
       if (running && l == 0) lds.vote[vp] = 1;
-      __syncthreads();
+      if constexpr (PERSIST) {
+        // (the vote is LDS traffic: __syncthreads would also wait for the history stores of
+        // add_step to be acknowledged by HBM - microseconds on the path every sweep workgroup
+        // of the group waits on)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else {
+        __syncthreads();
+      }
       const int any = __builtin_amdgcn_readfirstlane(*(volatile int*)&lds.vote[vp]);
       if (threadIdx.x == 0) lds.vote[(vp + 2) % 3] = 0;
       if (!any) break;
@@ -1955,8 +2009,8 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
       if (!plain) {
         // M:905-917
         bool shut = !r.shutting && (R.n - r.loop_i) < R.tail;
-        if (!shut && R.auto_mode && !r.shutting && floor_mod(r.loop_i, 1000) == 0 &&
-            r.loop_i > 2 * R.sts) {
+        if (!shut && R.auto_mode && !r.shutting &&
+            (PERSIST ? ph.m1000 == 0 : floor_mod(r.loop_i, 1000) == 0) && r.loop_i > 2 * R.sts) {
           __threadfence();
           ring.nh = r.nh;
           ring.length = r.length;
@@ -1970,6 +2024,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
           r.T = 1.0;
           r.shutting = 1;
           r.loop_i = R.n - R.tail;
+          if constexpr (PERSIST) ph.set(r.loop_i, R.sts);
         }
       }
       // M:918 walker-take-step: proposal
@@ -2039,8 +2094,18 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
 #endif
     if constexpr (PERSIST) {
       bool lost = false;
+      MHX_TIMC(lds, 7);  // (persistent master: publishing + the draws made ahead)
+#ifdef MHX_PERSIST_TIMING  // (measurement build: the master's iteration = controller + wait)
+      const unsigned long long tw0 = __builtin_readcyclecounter();
+      pt_ctrl += tw0 - pt_last;
+#endif
       prob1 = split_logpost<Spec, true>(P, S, c, running, lds, w, &ll, &lp,
                                         (unsigned long long)(it + 1), &lost);
+#ifdef MHX_PERSIST_TIMING
+      pt_last = __builtin_readcyclecounter();
+      pt_wait += pt_last - tw0;
+      ++pt_n;
+#endif
       if (__builtin_amdgcn_readfirstlane((int)lost)) {
         // the sweep workgroups did not answer (not all of them were on the GPU): nothing was
         // judged - the proposal is taken back (the next launch draws it again) and this chain's
@@ -2082,7 +2147,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
       MHX_TIMC(lds, 5);
     }
     if (plain) {
-      r.loop_i++;
+      r.loop_i++;  // (nothing under `plain` looks at the loop index's phases)
       continue;
     }
     const int64_t i = r.loop_i;
@@ -2099,8 +2164,8 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     }
     // regular l-matrix updating M:929-942
     if (i > 0) {
-      const bool m200 = floor_mod(i, 200) == 0;
-      const bool msts = !r.shutting && floor_mod(i, 2 * R.sts) == 0;
+      const bool m200 = PERSIST ? ph.m200 == 0 : floor_mod(i, 200) == 0;
+      const bool msts = !r.shutting && (PERSIST ? ph.msts == 0 : floor_mod(i, 2 * R.sts) == 0);
       if (m200 || msts) {
         l_stale = true;  // (PERSIST: the factor may change below)
         __threadfence();
@@ -2142,8 +2207,15 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
       }
     }
     MHX_TIMC(lds, 6);
-    if (r.status == MHX_CHAIN_RUNNING) r.loop_i++;
+    if (r.status == MHX_CHAIN_RUNNING) {
+      r.loop_i++;
+      if constexpr (PERSIST) ph.step(R.sts);
+    }
   }
+#ifdef MHX_PERSIST_TIMING
+  if (PERSIST && w == 0 && l == 0 && pt_n) persist_trace(pt_ctrl, pt_wait, 0, pt_n);
+  (void)pt_rt0; (void)pt_c0;
+#endif
   if (valid) {
     if (r.status == MHX_CHAIN_RUNNING && r.loop_i >= R.n) r.status = MHX_CHAIN_DONE;
     chain_store(S, c, d, r);
@@ -2273,8 +2345,17 @@ __device__ __forceinline__ bool persist_poll(const ChainState& S, int64_t c, int
   const int nlines = (d + 14) / 15;  // lines of the block that carry parameters
   unsigned long long q = 0;
   bool ok = false;
+  // A waiting wave must not take issue slots from a working one (VALU issue goes to the highest
+  // priority, then to the oldest wave; two workgroups of the launch share most CUs): waiting is
+  // done at priority 0, the masters' controllers - the serial part of every round - at 3, the
+  // sweeps in between (tile_prio moves within 0 ... 3 inside a tile).  Same box, us per
+  // iteration on 1e5 points with | without: 64 walkers 11.95 | 12.65, 128: 14.1 | 15.2,
+  // 256: 19.2 | 20.2, 512: 30.9 | 32.4 (8 and 16 walkers, one workgroup per CU: 9.7 | 9.8).
+  MHX_PERSIST_PRIO(0);
   for (unsigned n = 0; n < kPersistPatience; ++n) {
-    q = __hip_atomic_load(msg + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (only the lines that carry parameters are read: a poll is a request to the level all XCDs
+    // share, and thousands of waves poll)
+    q = (l >> 4) < nlines ? __hip_atomic_load(msg + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     const bool is_tag = (l & 15) == 15 && (l >> 4) < nlines;
     unsigned f = (l & 15) != 15 ? persist_fold(q) : 0u;
     f ^= (unsigned)__shfl_xor((int)f, 1, kWave);
@@ -2293,6 +2374,7 @@ __device__ __forceinline__ bool persist_poll(const ChainState& S, int64_t c, int
   }
   const unsigned gen0 = (unsigned)__builtin_amdgcn_readlane((int)q, 15);
   *word = q;
+  MHX_PERSIST_PRIO(1);
   return ok && !(gen0 & (unsigned)kPersistStop);
 }
 // TS = false: a handful of chains, grid (1 + slices, chains): workgroup (0, c) keeps only its wave
@@ -2364,6 +2446,7 @@ __device__ __forceinline__ void k_persist_body(const ProblemDesc* __restrict__ P
     bool alive = valid;
 #ifdef MHX_PERSIST_TIMING  // (measurement build: where a sweep workgroup's round goes)
     unsigned long long t_poll = 0, t_vote = 0, t_sweep = 0, t0 = __builtin_readcyclecounter(), rounds = 0;
+    unsigned long long s_poll = 0, s_vote = 0, s_sweep = 0;
 #define MHX_PT(acc) do { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - t0; t0 = n_; } while (0)
 #else
 #define MHX_PT(acc) do { } while (0)
@@ -2383,16 +2466,8 @@ __device__ __forceinline__ void k_persist_body(const ProblemDesc* __restrict__ P
       if (threadIdx.x == 0) lds.vote[(vp + 2) % 3] = 0;
       MHX_PT(t_vote);
 #ifdef MHX_PERSIST_TIMING
-      if (!any && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0) {
-        printf("sweep wg (1,0) wave 0: rounds %llu, cycles per round: poll %llu vote %llu sweep %llu\n", rounds,
-               t_poll / (rounds + 1), t_vote / (rounds + 1), t_sweep / (rounds + 1));
-#ifdef MHX_X_TIMING
-        printf("   inside the sweep (MHX_TIM phases 0-7, cycles per round): %llu %llu %llu %llu %llu %llu %llu %llu\n",
-               lds.tim[0][0] / (rounds + 1), lds.tim[0][1] / (rounds + 1), lds.tim[0][2] / (rounds + 1),
-               lds.tim[0][3] / (rounds + 1), lds.tim[0][4] / (rounds + 1), lds.tim[0][5] / (rounds + 1),
-               lds.tim[0][6] / (rounds + 1), lds.tim[0][7] / (rounds + 1));
-#endif
-      }
+      if (!any && threadIdx.x == 0) persist_trace(t_poll, t_vote, t_sweep, rounds);
+      (void)s_poll; (void)s_vote; (void)s_sweep;
       ++rounds;
 #ifdef MHX_X_TIMING
       if (round == 0 && l == 0) { for (int k = 0; k < 8; ++k) lds.tim[w][k] = 0; }
@@ -2421,8 +2496,12 @@ __global__ __launch_bounds__(kThreads) void k_persist(const ProblemDesc* __restr
                                                       int plain) {
   k_persist_body<Spec, false>(Pp, nullptr, S, R, 0, max_iters, plain);
 }
+// (registers for four waves per SIMD, as k_adaptive: two workgroups of the w8 family on a CU -
+// without the bound the two-peak kernel took 132 VGPRs, ONE workgroup fitted a CU, and the 400
+// workgroups of a 64-walker launch ran as two shifts: twice the time, found in the per-workgroup
+// trace of tools/debug/persist_ts_timing.py)
 template <class Spec>
-__global__ __launch_bounds__(kThreads) void k_persist_ts(const ProblemDesc* __restrict__ Pp,
+__global__ __launch_bounds__(kThreads, 4) void k_persist_ts(const ProblemDesc* __restrict__ Pp,
                                                          const FnDesc* __restrict__ slices,
                                                          ChainState S, RunDesc R, int n_slices,
                                                          int64_t max_iters, int plain) {

@@ -69,6 +69,9 @@ struct Family {
   // chains), every workgroup resident at once (the caller checks)
   hipError_t (*persist)(int spec, hipStream_t st, const ProblemDesc* P, const ChainState& S,
                         const RunDesc& R, int slices, int64_t max_iters, int plain);
+  // workgroups of the persistent kernel (ts: the tile-sliced one) a CU holds at once, as the
+  // runtime's occupancy calculator sees the compiled kernel (0: not compiled for this spec)
+  int (*persist_per_cu)(int spec, int ts);
   // ... the same for the tile-sliced mode (k_persist_ts): grid (1 + n_slices, chain groups)
   hipError_t (*persist_ts)(int spec, hipStream_t st, const ProblemDesc* P, const FnDesc* slices,
                            const ChainState& S, const RunDesc& R, int n_slices, int64_t max_iters,

@@ -325,7 +325,7 @@ static std::string generate(const std::vector<UserExpr>& models,
          "extern \"C\" __global__ __launch_bounds__(MHX_USER_THREADS) void mhx_user_persist(\n"
          "    const ProblemDesc* P, ChainState S, RunDesc R, int64_t max_iters, int plain) {\n"
          "  k_persist_body<UserSpec, false>(P, nullptr, S, R, 0, max_iters, plain);\n}\n"
-         "extern \"C\" __global__ __launch_bounds__(MHX_USER_THREADS) void mhx_user_persist_ts(\n"
+         "extern \"C\" __global__ __launch_bounds__(MHX_USER_THREADS, 4) void mhx_user_persist_ts(\n"
          "    const ProblemDesc* P, const FnDesc* slices, ChainState S, RunDesc R, int n_slices,\n"
          "    int64_t max_iters, int plain) {\n"
          "  k_persist_body<UserSpec, true>(P, slices, S, R, n_slices, max_iters, plain);\n}\n";
@@ -681,6 +681,13 @@ hipError_t rtc_launch_persist(const UserProgram& p, hipStream_t st, const Proble
   return hipModuleLaunchKernel(p.f_persist, 1u + (unsigned)slices, (unsigned)S.n_chains, 1,
                                (unsigned)p.fam->threads, 1, 1, (unsigned)p.fam->lds_bytes, st, args,
                                nullptr);
+}
+int rtc_persist_per_cu(const UserProgram& p, int ts) {
+  int n = 0;
+  hipFunction_t f = ts ? p.f_persist_ts : p.f_persist;
+  if (!f || hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, p.fam->threads, p.fam->lds_bytes) != hipSuccess)
+    return 0;
+  return n;
 }
 hipError_t rtc_launch_persist_ts(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                                  const FnDesc* slices, const ChainState& S, const RunDesc& R,

@@ -94,6 +94,7 @@ hipError_t rtc_launch_adaptive(const UserProgram& p, hipStream_t st, const Probl
 hipError_t rtc_launch_persist(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                               const ChainState& S, const RunDesc& R, int slices, int64_t max_iters,
                               int plain);
+int rtc_persist_per_cu(const UserProgram& p, int ts);
 hipError_t rtc_launch_persist_ts(const UserProgram& p, hipStream_t st, const ProblemDesc* P,
                                  const FnDesc* slices, const ChainState& S, const RunDesc& R,
                                  int n_slices, int64_t max_iters, int plain);

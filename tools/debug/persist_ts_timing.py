@@ -5,8 +5,9 @@ import lisp_mcmc_amd as mhx
 import problems as pb
 os.environ.pop("MHX_SPLIT", None)
 os.environ["MHX_PERSIST_TS"] = "1"
+# (needs a library built with -DMHX_PERSIST_TIMING [-DMHX_X_TIMING=1]: MHX_LIBRARY=...)
 big = pb.two_peak(n=100000, seed=3)
-for chains in (64,):
+for chains in (1, 64):
     e = big.engine(mhx, chains, seed=9)
     print(e.kernel_name())
     e.init_chains(pb.perturbed(big.theta_star, chains, 0.01, seed=2))
