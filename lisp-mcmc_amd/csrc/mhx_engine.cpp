@@ -462,6 +462,10 @@ int choose_tsplit(const mhx_engine* e, const Family& fam, bool capable, int64_t 
 // (s + 1) per_k) of its dataset, as a FnDesc of its own (what k_split_tsweep hands to sweep()).
 int build_ts_table(mhx_engine* e, int ts) {
   std::vector<FnDesc> tab((size_t)e->P.K * ts);
+  // one function, one window per slice, one persistent launch: a sweep workgroup's window stays
+  // in its LDS from its first round on (sweep(): FnDesc::solo; no DMA, no tile barriers and no
+  // layout vote in the rounds after it)
+  bool resident = e->persist && e->P.K == 1 && kPadPoints <= 2 * e->fam->tile_points;
   for (int k = 0; k < e->P.K; ++k) {
     const FnDesc& f = e->P.fn[k];
     const int64_t nwin = (f.n + kPadPoints - 1) / kPadPoints;
@@ -471,6 +475,7 @@ int build_ts_table(mhx_engine* e, int ts) {
       const int64_t off = (int64_t)sl * per * kPadPoints;
       g.lik_const = 0.0;
       g.solo = 0;
+      resident = resident && per == 1;
       if (off >= f.n) {
         g.n = 0;
         g.n_tiles = 0;
@@ -488,6 +493,9 @@ int build_ts_table(mhx_engine* e, int ts) {
       tab[(size_t)k * ts + sl] = g;
     }
   }
+  const char* nr = getenv("MHX_NO_RESIDENT_SLICES");
+  if (resident && !(nr && atoi(nr) != 0))
+    for (FnDesc& g : tab) g.solo = g.n_tiles > 0 ? 1 : 0;
   if (e->ts_table.n < tab.size() && e->ts_table.alloc(tab.size(), false) != hipSuccess)
     return fail(MHX_ENOMEM, "hipMalloc of the slice table failed");
   HIP_TRY(hipMemcpy(e->ts_table.p, tab.data(), tab.size() * sizeof(FnDesc), hipMemcpyHostToDevice));
@@ -813,7 +821,7 @@ int finalize_problem(mhx_engine* e) {
       e->persist = want && persist_allowed(e) && slices >= (e->tsplit ? 2 : 1) &&
                    units * (1 + slices) <= cap;
       (void)np_;
-      if (e->persist && e->tsplit && slices != e->split_slices) {
+      if (e->persist && e->tsplit) {  // (the table of the persistent form: fewer slices, resident windows)
         const int rc = build_ts_table(e, (int)slices);
         if (rc != MHX_OK) return rc;
         e->split_slices = (int)slices;

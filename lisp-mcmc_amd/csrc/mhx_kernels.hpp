@@ -414,6 +414,9 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
   static_assert(kSeedPts % 16 == 0 && (kPadPoints / kWave) % kSeedPts == 0, "seeds per window");
   (void)nw;
   if (nt == 0) return 0.0;
+  // (Also: a sweep workgroup of the tile-sliced persistent kernel whose slice is ONE window walks
+  // the same two tiles round after round - buffer 0 and buffer 1 - and takes them from memory in
+  // its first round only: build_ts_table.)
   // A problem with ONE function of ONE tile (test.lisp's 334 points) walked by a single
   // workgroup keeps that tile in LDS for the whole launch: after the first sweep there is no DMA
   // and no barrier left in here, which takes the L2 round trip out of every step of a
@@ -466,6 +469,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
 #ifndef MHX_NO_TILE_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
+    if (have) return;  // (a resident window: both its tiles are where an earlier sweep put them)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tcur + 2 < nt) tile_dma<NARR>(f, tcur + 2, lds, bufc, w);
@@ -479,7 +483,7 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
     (void)wi;
     // buffer buf^1 was last read in tile t-1, which every wave left through the barrier; (two
     // tiles per window: tile t itself was sent for by the previous window's mid_hook)
-    if (t + 1 < nt) tile_dma<NARR>(f, t + 1, lds, buf ^ 1, w);
+    if (t + 1 < nt && !have) tile_dma<NARR>(f, t + 1, lds, buf ^ 1, w);
     // Which Gaussian peaks this window needs (those that cannot change any of its sums by even
     // one bit are left out: PeaksModel::tile_mask; exact, so the results do not depend on it),
     // and whether the window can take the table exp: decided per WINDOW for such models, so one
@@ -1917,7 +1921,8 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
   unsigned long long pt_ctrl = 0, pt_wait = 0, pt_n = 0, pt_last = __builtin_readcyclecounter();
   const unsigned long long pt_rt0 = __builtin_amdgcn_s_memrealtime(), pt_c0 = pt_last;
 #endif
-  bool have_pre = false, have_lz = false, l_stale = true, stop_sent = false;
+  bool have_pre = false, have_lz = false, l_stale = true, stop_sent = false, early = false;
+  (void)early;
   (void)lz_pre; (void)have_lz;
   (void)stop_sent;
   // (one copy per master wave of the workgroup where they all fit, else the factor stays in HBM)
@@ -1990,17 +1995,15 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     // reduction with two): a running wave raises flag it % 3, everybody reads it after the
     // barrier, and the flag of iteration it + 2 - last read before the previous barrier, next
     // written after the next one - is lowered.
-    {
+    if constexpr (PERSIST) {
+      // (a master wave walks alone: nothing in this loop is shared between the waves of its
+      // workgroup - no tiles, the factor and the proposal in per-wave LDS - so a chain that has
+      // ended leaves, and nobody waits at a barrier for the slowest of eight chains)
+      if (!running) break;
+    } else {
       const int vp = (int)(it % 3);
       if (running && l == 0) lds.vote[vp] = 1;
-      if constexpr (PERSIST) {
-        // (the vote is LDS traffic: __syncthreads would also wait for the history stores of
-        // add_step to be acknowledged by HBM - microseconds on the path every sweep workgroup
-        // of the group waits on)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      } else {
-        __syncthreads();
-      }
+      __syncthreads();
       const int any = __builtin_amdgcn_readfirstlane(*(volatile int*)&lds.vote[vp]);
       if (threadIdx.x == 0) lds.vote[(vp + 2) % 3] = 0;
       if (!any) break;
@@ -2067,7 +2070,8 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     }
     if constexpr (PERSIST) {  // ... to the chain's sweep workgroups of this same launch
       if (running) {
-        persist_publish(S, c, d, thp, (unsigned long long)(it + 1));
+        if (!early) persist_publish(S, c, d, thp, (unsigned long long)(it + 1));
+        early = false;
         rv_pre = rng_lane_value(S.seed, gchain, r.draw, d, &lg_pre);  // (the next iteration's)
         have_pre = true;
         if (l_in_lds && !l_stale) {  // ... and its L z (the factor changes only at adaptation ticks)
@@ -2143,6 +2147,25 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
       const double th_now = take ? (l < d ? lds.prop[w][l] : 0.0)
                                  : (cur_in_lds ? (l < d ? lds.cur[w][l] : 0.0) : chain_theta(S, c, d));
       if (take && cur_in_lds && l < d) lds.cur[w][l] = th_now;
+      if constexpr (PERSIST) {
+        // The sweep workgroups wait for the next proposal, and on most iterations everything it
+        // is made of is known here: the position (th_now), the draw made ahead and its L z.  It
+        // goes out NOW, before :add-step, annealing, the adaptation test and the loop's top -
+        // which then run while the sweeps work.  Only where none of them can change the
+        // proposal or end the walk: no adaptation tick at this index, no shut-down or
+        // acceptance look at the next, not the launch's or the walk's last iteration, not an
+        // iteration that looks at the stop flag.  The loop's top still forms the proposal its
+        // own way (the same operands, the same bits) and only skips the publishing.
+        const int64_t i1 = r.loop_i + 1;
+        const bool tick = r.loop_i > 0 && (ph.m200 == 0 || (!r.shutting && ph.msts == 0));
+        const bool look = !r.shutting && ((R.n - i1) < R.tail ||
+                                          (R.auto_mode && ph.m1000 == 999 && i1 > 2 * R.sts));
+        if (have_pre && have_lz && !l_stale && it + 1 < max_iters && i1 < R.n && ((it + 1) & 15) != 0 &&
+            (plain || (!tick && !look))) {
+          persist_publish(S, c, d, lz_pre + th_now, (unsigned long long)(it + 2));
+          early = true;
+        }
+      }
       add_step(S, c, d, r, th_now, take);
       MHX_TIMC(lds, 5);
     }
@@ -2444,6 +2467,11 @@ __device__ __forceinline__ void k_persist_body(const ProblemDesc* __restrict__ P
     lds_begin(lds);
     const int slice = (int)blockIdx.x - 1;
     bool alive = valid;
+    // One function whose slice is a resident window (build_ts_table): after the first round -
+    // the tiles fetched together, behind barriers - the eight waves of the workgroup share
+    // nothing but read-only LDS, and each follows its own chain: polls, sweeps, answers, leaves
+    // when the chain ends.  (Otherwise the waves stage tiles together round after round.)
+    const bool free_run = P.K == 1 && slices[slice].solo != 0 && slices[slice].n_tiles > 0;
 #ifdef MHX_PERSIST_TIMING  // (measurement build: where a sweep workgroup's round goes)
     unsigned long long t_poll = 0, t_vote = 0, t_sweep = 0, t0 = __builtin_readcyclecounter(), rounds = 0;
     unsigned long long s_poll = 0, s_vote = 0, s_sweep = 0;
@@ -2456,18 +2484,30 @@ __device__ __forceinline__ void k_persist_body(const ProblemDesc* __restrict__ P
       if (alive) alive = persist_poll(S, c, d, round, &q);
       MHX_PT(t_poll);
       const bool active = alive;
-      // anybody of the group still walking?  (a flag and ONE barrier, as in k_adaptive_body)
-      const int vp = (int)(round % 3);
-      if (active && l == 0) lds.vote[vp] = 1;
       if (active && (l & 15) != 15 && (l >> 4) < (d + 14) / 15)
         lds.prop[w][(l >> 4) * 15 + (l & 15)] = __longlong_as_double((long long)q);
-      __syncthreads();
-      const int any = __builtin_amdgcn_readfirstlane(*(volatile int*)&lds.vote[vp]);
-      if (threadIdx.x == 0) lds.vote[(vp + 2) % 3] = 0;
+      int any;
+      if (free_run && round > 0) {
+        // (the window is in LDS: this wave's rounds need nothing of the other waves any more)
+        any = active ? 1 : 0;
+      } else {
+        // anybody of the group still walking?  (a flag and ONE barrier, as in k_adaptive_body)
+        const int vp = (int)(round % 3);
+        if (active && l == 0) lds.vote[vp] = 1;
+        __syncthreads();
+        any = __builtin_amdgcn_readfirstlane(*(volatile int*)&lds.vote[vp]);
+        if (threadIdx.x == 0) lds.vote[(vp + 2) % 3] = 0;
+      }
       MHX_PT(t_vote);
 #ifdef MHX_PERSIST_TIMING
       if (!any && threadIdx.x == 0) persist_trace(t_poll, t_vote, t_sweep, rounds);
       (void)s_poll; (void)s_vote; (void)s_sweep;
+#ifdef MHX_X_TIMING
+      if (!any && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0 && rounds)
+        printf("sweep wg (1,0) wave 0, MHX_TIM phases 0-7, cycles per round: %llu %llu %llu %llu %llu %llu %llu %llu\n",
+               lds.tim[0][0] / rounds, lds.tim[0][1] / rounds, lds.tim[0][2] / rounds, lds.tim[0][3] / rounds,
+               lds.tim[0][4] / rounds, lds.tim[0][5] / rounds, lds.tim[0][6] / rounds, lds.tim[0][7] / rounds);
+#endif
       ++rounds;
 #ifdef MHX_X_TIMING
       if (round == 0 && l == 0) { for (int k = 0; k < 8; ++k) lds.tim[w][k] = 0; }
