@@ -440,7 +440,12 @@ int choose_tsplit(const mhx_engine* e, const Family& fam, bool capable, int64_t 
       heavy = heavy || fd.lik == MHX_LIK_POISSON || fd.lik == MHX_LIK_EXPR ||
               fd.model == MHX_MODEL_PVOIGT2 || fd.model == MHX_MODEL_EXPR;
     }
-    if (C < W || groups >= 256) return 0;
+    if (groups >= 256) return 0;
+    // fewer walkers than a workgroup has waves: the per-chain split mode - unless the persistent
+    // form is allowed, whose sweep workgroups walk LDS tiles with peak skipping and the
+    // recurrence, one window per wave however long the dataset (a single walker on 1e5 points
+    // 7.6 -> 6.4 us per step, on 1e6 points 25.4 -> 11.1; 20000 points: 6.2 against 6.7, left alone)
+    if (C < W && (cap_ts <= 0 || nwin < 12)) return 0;
     if (nwin < (heavy ? 4 : 12)) {
       // too short for two launches per iteration: as one persistent launch, or not at all
       if (nwin < (heavy ? 2 : 4) || groups * (1 + nwin) > cap_ts) return 0;

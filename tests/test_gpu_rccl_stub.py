@@ -445,8 +445,9 @@ def test_config5_in_its_eight_engine_form_on_one_gpu(tmp_path):
     assert sum(c.startswith("CommDestroy") for c in calls) == 8
 
 
-def test_persistent_launch_whose_sweepers_never_come_is_taken_back(tmp_path):
-    """k_persist counts on all its workgroups being on the GPU at once.  When they are not
+@pytest.mark.parametrize("form,chains", [("split", 2), ("tsplit", 20)])
+def test_persistent_launch_whose_sweepers_never_come_is_taken_back(tmp_path, form, chains):
+    """k_persist and k_persist_ts count on all their workgroups being on the GPU at once.  When they are not
     (another kernel holds the GPU for longer than a master's patience) the master takes its
     proposal back, the launch ends, mhx_adaptive_advance answers MHX_EDEVICE with no chain
     touched, and the engine goes back to two launches per iteration - after a new begin the walk is
@@ -455,12 +456,15 @@ def test_persistent_launch_whose_sweepers_never_come_is_taken_back(tmp_path):
     env = dict(os.environ, MHX_LIBRARY=HOOKS, MHX_TEST_LOSE_SWEEPERS="1")
     for k in ("MHX_SPLIT", "MHX_TSPLIT", "MHX_NO_PERSIST"):
         env.pop(k, None)
+    if form == "split":
+        env["MHX_TSPLIT"] = "0"  # (the per-chain persistent form)
     body = PRELUDE + textwrap.dedent("""
+        FORM, CHAINS = "@FORM@", @CHAINS@
         s = pb.two_peak(n=30000, seed=3)
-        th0 = pb.perturbed(s.theta_star, 2, 0.01, seed=2)
-        e = s.engine(mhx, 2, seed=9)
+        th0 = pb.perturbed(s.theta_star, CHAINS, 0.01, seed=2)
+        e = s.engine(mhx, CHAINS, seed=9)
         e.init_chains(th0)
-        assert "persistent split x" in e.kernel_name(), e.kernel_name()
+        assert "persistent " + FORM + " x" in e.kernel_name(), e.kernel_name()
         before = e.state()
         e.adaptive_begin(900, 10.0, 1)
         try:
@@ -477,11 +481,11 @@ def test_persistent_launch_whose_sweepers_never_come_is_taken_back(tmp_path):
             raise SystemExit("the run should be over")
         except mhx.MhxError as ex:
             assert ex.code == mhx.capi.ESTATE
-        assert "persistent" not in e.kernel_name() and "split x" in e.kernel_name(), e.kernel_name()
+        assert "persistent" not in e.kernel_name() and " " + FORM + " x" in e.kernel_name(), e.kernel_name()
         e.adaptive_begin(900, 10.0, 1)
         e.adaptive_advance(1 << 40)
         os.environ["MHX_NO_PERSIST"] = "1"
-        ref = s.engine(mhx, 2, seed=9)
+        ref = s.engine(mhx, CHAINS, seed=9)
         ref.init_chains(th0)
         ref.adaptive_begin(900, 10.0, 1)
         ref.adaptive_advance(1 << 40)
@@ -489,7 +493,7 @@ def test_persistent_launch_whose_sweepers_never_come_is_taken_back(tmp_path):
         for k in ("theta", "logpost", "age", "length"):
             assert np.array_equal(a[k], b[k]), k
         print("ok", flush=True)
-    """)
+    """).replace("@FORM@", form).replace("@CHAINS@", str(chains))
     out = subprocess.run([sys.executable, "-c", body], capture_output=True, text=True, env=env, timeout=600)
     assert "ok" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
     assert out.returncode == 0

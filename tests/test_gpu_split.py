@@ -309,13 +309,15 @@ def test_split_mode_is_chosen_by_batch_and_dataset_size(mhx):
     s_mid = pb.two_peak(n=20000, seed=1)
     s_8k = pb.two_peak(n=8192, seed=1)
     s_short = pb.two_peak(n=3000, seed=1)
-    # one chain's points over many workgroups below 8 chains; from 8 on groups of 8 chains on
+    # one chain's points over many workgroups below 8 chains on datasets of fewer than 12 windows
+    # (and everywhere with MHX_NO_PERSIST=1); otherwise groups of (up to) 8 chains on
     # slices of whole windows ("tsplit": about 512 workgroups in the sweep launch) - as ONE
     # persistent launch per portion of iterations where the GPU holds all its workgroups at once
     # with at least three quarters of the default slicing, else as two launches per iteration;
     # the batch kernels from 256 workgroups on and for short datasets.  Shorter datasets only as
     # a persistent launch: per chain where that fits, else tile-sliced from 4 windows on.
-    for spec, chains, want in ((s_long, 1, "persistent split x24"), (s_long, 4, "persistent split x24"),
+    for spec, chains, want in ((s_long, 1, "persistent tsplit x49"), (s_long, 4, "persistent tsplit x49"),
+                               (s_mid, 1, "persistent split x4"),
                                (s_long, 16, "persistent tsplit x49"), (s_long, 256, "persistent tsplit x13"),
                                (s_long, 512, "persistent tsplit x6"), (s_long, 1024, " tsplit x4"),
                                (s_long, 2048, None), (s_short, 1, None), (s_short, 64, None),
@@ -330,7 +332,7 @@ def test_split_mode_is_chosen_by_batch_and_dataset_size(mhx):
         os.environ[var] = "0" if var == "MHX_PERSIST_TS" else "1"
         try:
             for spec, chains, want in ((s_long, 256, " tsplit x16"), (s_long, 512, " tsplit x8"),
-                                       (s_8k, 256, None), (s_mid, 256, " split x4")):
+                                       (s_8k, 256, None), (s_mid, 256, " split x4"), (s_long, 4, " split x24")):
                 e, name = engine(mhx, spec, chains, None)
                 assert ((want in name) if want else ("split" not in name)) and "persistent t" not in name, (var, chains, name)
                 e.close()
@@ -517,13 +519,15 @@ def test_slot_map_grows_when_the_problem_changes_the_mode(mhx):
 
 
 def persist_pair(mhx, make_engine):
-    """(persistent split mode - the default for a handful of chains -, the two launches per
-    iteration of rounds 1-3: MHX_NO_PERSIST=1), finalised under their settings"""
+    """(the per-chain persistent split mode - the default for a handful of chains on datasets of
+    fewer than 12 windows; MHX_TSPLIT=0 keeps the longer ones of these tests in it -, the two
+    launches per iteration of rounds 1-3: MHX_NO_PERSIST=1), finalised under their settings"""
     out = []
     for flag in (None, "1"):
         old = {k: os.environ.get(k) for k in ("MHX_SPLIT", "MHX_TSPLIT", "MHX_NO_PERSIST")}
         for k in old:
             os.environ.pop(k, None)
+        os.environ["MHX_TSPLIT"] = "0"  # (the per-chain form is what these tests are about)
         if flag:
             os.environ["MHX_NO_PERSIST"] = flag
         try:
@@ -590,6 +594,7 @@ def test_persistent_split_mode_with_a_model_compiled_at_run_time_and_the_stop_fl
     for flag in (None, "1"):
         for k in ("MHX_SPLIT", "MHX_TSPLIT", "MHX_NO_PERSIST"):
             os.environ.pop(k, None)
+        os.environ["MHX_TSPLIT"] = "0"  # (the per-chain form)
         if flag:
             os.environ["MHX_NO_PERSIST"] = flag
         try:
@@ -598,6 +603,7 @@ def test_persistent_split_mode_with_a_model_compiled_at_run_time_and_the_stop_fl
             w.engine.kernel_name()
         finally:
             os.environ.pop("MHX_NO_PERSIST", None)
+            os.environ.pop("MHX_TSPLIT", None)
         ws.append(w)
     assert "persistent split x" in ws[0].engine.kernel_name() and "rtc[" in ws[0].engine.kernel_name()
     assert "persistent" not in ws[1].engine.kernel_name()
@@ -651,7 +657,13 @@ def ts_persist_pair(mhx, spec, chains, ts, **kw):
     return out[0][0], out[1][0]
 
 
-@pytest.mark.parametrize("name,make,lscale,chains,ask", TS_CASES, ids=[c[0] for c in TS_CASES])
+TS_PERSIST_CASES = TS_CASES + [   # fewer walkers than a workgroup has waves: the default from 12 windows on
+    ("two_peak_single_walker", lambda: pb.two_peak(n=30000, seed=3), None, 1, 15),
+    ("two_peak_three_walkers", lambda: pb.two_peak(n=40000, seed=23), None, 3, 20),
+]
+
+
+@pytest.mark.parametrize("name,make,lscale,chains,ask", TS_PERSIST_CASES, ids=[c[0] for c in TS_PERSIST_CASES])
 def test_persistent_tile_sliced_mode_equals_the_two_launch_form(mhx, name, make, lscale, chains, ask):
     """VERDICT r3 item 6, the batches of 8 ... a few hundred walkers: ONE launch per portion of
     iterations (k_persist_ts) - the 8 waves of a group's master workgroup run the chains'
