@@ -1244,6 +1244,16 @@ __device__ __forceinline__ void persist_trace(unsigned long long a, unsigned lon
 #define MHX_PERSIST_PRIO(P) __builtin_amdgcn_s_setprio(P)
 #endif
 constexpr unsigned kPersistPatience = 1u << 20;   // polls (a memory round trip apart) before giving up
+// xor over each row of 16 lanes, left in all of them: four rotations within the row (DPP: a few
+// cycles each, where a shuffle is a trip through the LDS crossbar - and this sits between a poll's
+// load coming back and the wave knowing what it has read)
+__device__ __forceinline__ unsigned persist_row_xor(unsigned f) {
+  f ^= (unsigned)__builtin_amdgcn_mov_dpp((int)f, 0x128, 0xf, 0xf, false);  // row_ror:8
+  f ^= (unsigned)__builtin_amdgcn_mov_dpp((int)f, 0x124, 0xf, 0xf, false);  // row_ror:4
+  f ^= (unsigned)__builtin_amdgcn_mov_dpp((int)f, 0x122, 0xf, 0xf, false);  // row_ror:2
+  f ^= (unsigned)__builtin_amdgcn_mov_dpp((int)f, 0x121, 0xf, 0xf, false);  // row_ror:1
+  return f;
+}
 constexpr int kPersistMaxParams = 60;             // four lines of 15 parameters and a tag
 typedef __attribute__((ext_vector_type(4))) unsigned int persist_u4;
 __device__ __forceinline__ void persist_store_pair(void* p, double v, unsigned long long gen) {
@@ -1270,10 +1280,7 @@ __device__ __forceinline__ void persist_publish(const ChainState& S, int64_t c, 
   const double v = __shfl(thp, e < kWave ? e : 0, kWave);
   const unsigned long long data = ((l & 15) != 15 && e < d) ? (unsigned long long)__double_as_longlong(v) : 0ull;
   unsigned f = (l & 15) != 15 ? persist_fold(data) : 0u;  // xor over the line's 15 data words
-  f ^= (unsigned)__shfl_xor((int)f, 1, kWave);
-  f ^= (unsigned)__shfl_xor((int)f, 2, kWave);
-  f ^= (unsigned)__shfl_xor((int)f, 4, kWave);
-  f ^= (unsigned)__shfl_xor((int)f, 8, kWave);
+  f = persist_row_xor(f);
   const unsigned long long word = (l & 15) == 15 ? (((unsigned long long)f << 32) | gen) : data;
   if ((l >> 4) <= (d > 0 ? (d - 1) / 15 : 3))  // the lines in use (a stop word: all four)
     __hip_atomic_store(m + l, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2381,10 +2388,7 @@ __device__ __forceinline__ bool persist_poll(const ChainState& S, int64_t c, int
     q = (l >> 4) < nlines ? __hip_atomic_load(msg + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     const bool is_tag = (l & 15) == 15 && (l >> 4) < nlines;
     unsigned f = (l & 15) != 15 ? persist_fold(q) : 0u;
-    f ^= (unsigned)__shfl_xor((int)f, 1, kWave);
-    f ^= (unsigned)__shfl_xor((int)f, 2, kWave);
-    f ^= (unsigned)__shfl_xor((int)f, 4, kWave);
-    f ^= (unsigned)__shfl_xor((int)f, 8, kWave);
+    f = persist_row_xor(f);
     // (lane 16 i + 15 now holds the fold of line i's data words - its own contribution was 0)
     const unsigned gen = (unsigned)q;
     const bool fresh = gen > (unsigned)round && (unsigned)(q >> 32) == f;
