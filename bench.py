@@ -644,6 +644,29 @@ def main():
             "dispatches": [pw_warm, pw_warm + pk["launches"]],   # among mhx_user_adaptive's
             "ratio_to_value": out["value"] / out["value_piecewise"]}
         pw.close()
+    # ... and the reference's own way of working: ONE walker (and a small batch of 64) on the same
+    # data.  Too few chains for the batch kernel: the likelihood sum is spread over sweep
+    # workgroups and a whole portion of iterations runs as one persistent launch (k_persist_ts;
+    # two launches per iteration until round 3).  Microseconds per iteration of a 1024-iteration
+    # stretch after 256 of warm-up, host clock around synchronised calls.
+    if (rank == 0 and not per_rank and n_gpus == 1 and not args.no_direct and args.workload == "c2"):
+        sb = {"what": "the same data walked by 1 and by 64 walkers (walker-adaptive-steps from theta*(1 + 1 %), "
+                      "T = 10): us per iteration over 1024 iterations after 256"}
+        for c in (1, 64):
+            small = Fleet(mhx, spec, c, devices, False, seed=0x5EED0005, chain_offset=first_id)
+            small.start(th0[:c], n_adapt, l0)
+            small.advance(256)
+            s0 = small.steps()
+            sync()
+            ts0 = time.perf_counter()
+            small.advance(1024)
+            sync()
+            tsb = time.perf_counter() - ts0
+            done = small.steps() - s0
+            sb["walkers_%d" % c] = {"us_per_iteration": tsb / 1024 * 1e6, "chain_steps_per_s": done / tsb,
+                                    "kernel": small.kernel_name(), "trapped": bool(small.trapped())}
+            small.close()
+        out["small_batches"] = sb
     if rank == 0 and not per_rank and n_gpus == 1 and not args.no_cpu:
         ncpu, cinfo = effective_cores()
         one = cpu_baseline(spec, th0, args.cpu_seconds * 0.4, n_adapt, 1, l0)

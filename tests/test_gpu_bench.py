@@ -35,6 +35,9 @@ def test_bench_line_at_the_drivers_arguments():
     assert r["kernel_ms_per_launch"] * 1e-3 <= d["ms_per_step"] * 1e-3 * 20 * 1.001
     assert d["build"]["id"].startswith("csrc:")
     assert d["value_direct_form"] > 0 and d["direct_form"]["ratio_to_value"] > 1.0
+    sb = d["small_batches"]
+    for k in ("walkers_1", "walkers_64"):   # (one persistent launch per portion: well under the 16-20 us of two launches)
+        assert "persistent tsplit" in sb[k]["kernel"] and 0 < sb[k]["us_per_iteration"] < 14 and not sb[k]["trapped"], sb
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["single_core"]["value"] > 0
     assert d["value"] > 1e3 * c["value"]
