@@ -345,6 +345,15 @@ static int persist_ts_wanted() {
   return s ? (atoi(s) != 0 ? 1 : 0) : -1;
 }
 int64_t persist_capacity(const mhx_engine* e, bool ts);
+// nwin windows cut into ts slices are ceil(nwin / ts) windows per slice - which may fill fewer
+// slices than ts: 49 windows in 16 slices are 13 slices of 4 (the last one of 1) and three empty
+// ones, whose workgroups would be launched (or, persistent, sit on a CU and poll) for nothing.
+// The sums are the same bits either way: an empty slice's partial sum is +0.
+static int64_t trim_slices(int64_t nwin, int64_t ts) {
+  if (ts <= 0 || nwin <= 0) return ts;
+  const int64_t per = (nwin + ts - 1) / ts;
+  return (nwin + per - 1) / per;
+}
 
 // Split mode (mhx_kernels.hpp): how many workgroups share one chain's likelihood sums, or 0 for
 // the batch kernels.  Worth it when the batch launch would leave most CUs without a workgroup
@@ -448,10 +457,14 @@ int choose_tsplit(const mhx_engine* e, const Family& fam, bool capable, int64_t 
     if (C < W && (cap_ts <= 0 || nwin < 12)) return 0;
     if (nwin < (heavy ? 4 : 12)) {
       // too short for two launches per iteration: as one persistent launch, or not at all
-      if (nwin < (heavy ? 2 : 4) || groups * (1 + nwin) > cap_ts) return 0;
+      // (a window per slice, or fewer slices of up to 4 windows where the GPU does not hold that
+      // many workgroups at once: 20000 points, 512 walkers x7 instead of the per-chain split
+      // mode's two launches)
+      const int64_t fit = std::min<int64_t>(nwin, cap_ts / groups - 1);
+      if (nwin < (heavy ? 2 : 4) || fit < 2 || (nwin + fit - 1) / fit > 4) return 0;
       const int pc = choose_split(e, fam, capable, cap_pc);
       if (pc > 0 && C * (1 + pc) <= cap_pc) return 0;  // (the per-chain persistent form)
-      return (int)nwin;
+      return (int)trim_slices(nwin, fit);
     }
     // measured (config 2's problem, chain-steps/s; slices 4 | 8 | 16 | 32 | 49):
     //   64 chains 1.5e6 | 2.1e6 | 2.6e6 | 3.1e6 | 3.1e6     256: 6.0e6 | 7.9e6 | 8.0e6 | 7.0e6 | 6.3e6
@@ -460,6 +473,7 @@ int choose_tsplit(const mhx_engine* e, const Family& fam, bool capable, int64_t 
     want = 512 / groups;
   }
   want = std::min<int64_t>(want, nwin);
+  if (!getenv("MHX_TSPLIT")) want = trim_slices(nwin, want);
   return want >= 2 ? (int)want : 0;
 }
 
@@ -523,19 +537,23 @@ const Family& choose_family(const mhx_engine* e) {
   return big ? family_w16() : family_w8();
 }
 
-// workgroups of the stepping kernels the GPU holds at once, with a tenth in hand: what a
-// persistent launch (k_persist, k_persist_ts) may ask for - its workgroups wait for one another
-// Workgroups of a persistent launch the GPU holds at once: CUs times what the occupancy
-// calculator gives the COMPILED kernel (registers, LDS and waves - an assumed "two per CU" was
-// wrong for a kernel of 132 VGPRs and cost half the speed, see k_persist_ts), less a tenth for
-// whatever else runs on the device.
+// Workgroups of a persistent launch (k_persist, k_persist_ts: they wait for one another) the GPU
+// holds at once: CUs times what the occupancy calculator gives the COMPILED kernel (registers,
+// LDS and waves - an assumed "two per CU" was wrong for a kernel of 132 VGPRs and cost half the
+// speed, see k_persist_ts).  Every slot: what the calculator promises is what the dispatcher
+// gives - 128 groups x (1 + 3) = 512 workgroups on 256 CUs ran in one shift, 55.9 us per
+// iteration against 72.0 of two launches - and a workgroup that finds its slot taken for a
+// while by another kernel of the process arrives late, within the masters' patience
+// (MHX_PERSIST_FILL=<per cent>: measurements).
 int64_t persist_capacity(const mhx_engine* e, bool ts) {
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus <= 0)
     cus = 256;
   const int per_cu = e->spec == SPEC_USER ? rtc_persist_per_cu(*e->user_prog, ts ? 1 : 0)
                                           : e->fam->persist_per_cu(e->spec, ts ? 1 : 0);
-  return (int64_t)cus * per_cu * 9 / 10;
+  int fill = 100;
+  if (const char* f = getenv("MHX_PERSIST_FILL")) fill = std::max(10, std::min(100, atoi(f)));
+  return (int64_t)cus * per_cu * fill / 100;
 }
 
 int finalize_problem(mhx_engine* e) {
@@ -818,9 +836,16 @@ int finalize_problem(mhx_engine* e) {
       // kernel took 132 VGPRs, one workgroup fitted a CU, and the launch ran in two shifts.)
       const int wanted = persist_ts_wanted();
       if (e->tsplit && !getenv("MHX_TSPLIT")) {
-        const int64_t fit = std::min<int64_t>(slices, cap / units - 1);
+        int64_t nwin_all = 1;
+        for (int k = 0; k < e->P.K; ++k)
+          nwin_all = std::max<int64_t>(nwin_all, (e->P.fn[k].n + kPadPoints - 1) / kPadPoints);
+        const int64_t fit = trim_slices(nwin_all, std::min<int64_t>(slices, cap / units - 1));
         const int64_t least = wanted > 0 ? 2 : std::max<int64_t>(2, (3 * slices + 3) / 4);
-        slices = fit >= least ? fit : 0;
+        // (fewer slices only where an iteration is short enough for the saved launches to
+        // matter: up to 32 windows per slice - 1e6 points, 1024 walkers: x3 500 us against the
+        // two launches' x4 424; 1e5 points, 1024 walkers: x3 55.9 against x4 72.0)
+        const bool short_rounds = fit > 0 && (nwin_all + fit - 1) / fit <= 32;
+        slices = fit >= least && (fit == slices || short_rounds || wanted > 0) ? fit : 0;
       }
       const bool want = e->tsplit ? wanted != 0 : true;
       e->persist = want && persist_allowed(e) && slices >= (e->tsplit ? 2 : 1) &&
@@ -1116,6 +1141,7 @@ int compact_tsplit(mhx_engine* e, const std::vector<int32_t>& st, int64_t runnin
                                           std::min<int64_t>(std::min<int64_t>(512 / groups, nwin), 512));
   if (e->persist && !forced)  // (every workgroup of a persistent launch on the GPU at once)
     ts = std::max<int64_t>(2, std::min<int64_t>(ts, persist_capacity(e, true) / groups - 1));
+  if (!forced) ts = std::max<int64_t>(2, trim_slices(nwin, ts));
   if (ts != e->split_slices) {
     const int rc = build_ts_table(e, (int)ts);
     if (rc != MHX_OK) return rc;

@@ -307,23 +307,28 @@ def test_split_single_walker_expression_and_many_steps(mhx):
 def test_split_mode_is_chosen_by_batch_and_dataset_size(mhx):
     s_long = pb.two_peak(n=100000, seed=1)
     s_mid = pb.two_peak(n=20000, seed=1)
+    s_1e6 = pb.two_peak(n=1000000, seed=1)
     s_8k = pb.two_peak(n=8192, seed=1)
     s_short = pb.two_peak(n=3000, seed=1)
     # one chain's points over many workgroups below 8 chains on datasets of fewer than 12 windows
     # (and everywhere with MHX_NO_PERSIST=1); otherwise groups of (up to) 8 chains on
     # slices of whole windows ("tsplit": about 512 workgroups in the sweep launch) - as ONE
     # persistent launch per portion of iterations where the GPU holds all its workgroups at once
-    # with at least three quarters of the default slicing, else as two launches per iteration;
-    # the batch kernels from 256 workgroups on and for short datasets.  Shorter datasets only as
+    # with at least three quarters of the default slicing (fewer slices than the default only
+    # up to 32 windows per slice), else as two launches per iteration;
+    # the batch kernels from 256 workgroups on and for short datasets.  (Slices that would stay
+    # empty are not asked for: 49 windows in 16 slices are 13 slices of 4 windows.)  Shorter datasets only as
     # a persistent launch: per chain where that fits, else tile-sliced from 4 windows on.
     for spec, chains, want in ((s_long, 1, "persistent tsplit x49"), (s_long, 4, "persistent tsplit x49"),
                                (s_mid, 1, "persistent split x4"),
                                (s_long, 16, "persistent tsplit x49"), (s_long, 256, "persistent tsplit x13"),
-                               (s_long, 512, "persistent tsplit x6"), (s_long, 1024, " tsplit x4"),
+                               (s_long, 512, "persistent tsplit x7"), (s_long, 1024, "persistent tsplit x3"),
+                               (s_1e6, 1024, " tsplit x4"), (s_long, 1536, " tsplit x2"),
                                (s_long, 2048, None), (s_short, 1, None), (s_short, 64, None),
                                (s_mid, 32, "persistent split x4"), (s_mid, 256, "persistent tsplit x10"),
-                               (s_mid, 1024, None), (s_8k, 4, "persistent split x2"),
-                               (s_8k, 256, "persistent tsplit x4"), (s_8k, 1024, None)):
+                               (s_mid, 1024, "persistent tsplit x3"), (s_mid, 1536, None),
+                               (s_8k, 4, "persistent split x2"), (s_8k, 256, "persistent tsplit x4"),
+                               (s_8k, 1024, "persistent tsplit x2"), (s_8k, 1536, None)):
         e, name = engine(mhx, spec, chains, None)
         assert (want in name) if want else ("split" not in name), (chains, name)
         e.close()
@@ -331,7 +336,7 @@ def test_split_mode_is_chosen_by_batch_and_dataset_size(mhx):
     for var in ("MHX_PERSIST_TS", "MHX_NO_PERSIST"):
         os.environ[var] = "0" if var == "MHX_PERSIST_TS" else "1"
         try:
-            for spec, chains, want in ((s_long, 256, " tsplit x16"), (s_long, 512, " tsplit x8"),
+            for spec, chains, want in ((s_long, 256, " tsplit x13"), (s_long, 512, " tsplit x7"),
                                        (s_8k, 256, None), (s_mid, 256, " split x4"), (s_long, 4, " split x24")):
                 e, name = engine(mhx, spec, chains, None)
                 assert ((want in name) if want else ("split" not in name)) and "persistent t" not in name, (var, chains, name)

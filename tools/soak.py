@@ -15,9 +15,14 @@ import lisp_mcmc_amd as mhx  # noqa: E402
 
 ok = True
 # SOAK_BIG=1: the batch kernels of the 16-wave family instead (4096 chains each)
+# SOAK_SMALL=1: the persistent split modes (1 ... 256 walkers: one launch per portion of iterations)
 BIG = os.environ.get("SOAK_BIG") == "1"
+SMALL = os.environ.get("SOAK_SMALL") == "1"
 for name, chains, small_l in ((("c2", 4096, False), ("c3", 4096, True), ("c4", 4096, False),
                                ("g23", 4096, False), ("poly7", 4096, False)) if BIG else
+                              (("c2", 1, False), ("c2", 5, False), ("c2", 64, False), ("c2", 256, False),
+                               ("c3", 16, True), ("c4", 64, False), ("g23", 24, False),
+                               ("poly7", 40, False)) if SMALL else
                               (("c2", 1024, False), ("c3", 256, True), ("c4", 512, False),
                                ("g23", 512, False), ("poly7", 1024, False))):
     spec, _, _, desc = bench.synth_workload(name)
