@@ -473,7 +473,17 @@ int choose_tsplit(const mhx_engine* e, const Family& fam, bool capable, int64_t 
     want = 512 / groups;
   }
   want = std::min<int64_t>(want, nwin);
-  if (!getenv("MHX_TSPLIT")) want = trim_slices(nwin, want);
+  if (!getenv("MHX_TSPLIT")) {
+    want = trim_slices(nwin, want);
+    // two or three slices as TWO LAUNCHES per iteration lose to the batch kernels on datasets
+    // that are not long (measured round 4, us per iteration, two launches | batch kernels:
+    //   1536 walkers x2: 5e4 points 76.5 | 56.7, 1e5: 102 | 90.8, 1e6: 690 | 846;
+    //   1100 walkers x3: 5e4 points 58.6 | 55.2, 1e5: 75.9 | 89.9) - unless the persistent
+    // form will take them (1024 walkers x3, 5e4 points: 35.5 | 49.1)
+    const int64_t pfit = cap_ts > 0 ? std::min<int64_t>(want, cap_ts / groups - 1) : 0;
+    const bool persistable = pfit >= std::max<int64_t>(2, (3 * want + 3) / 4) && persist_ts_wanted() != 0;
+    if (!persistable && ((want == 2 && nwin < 128) || (want == 3 && nwin < 32))) return 0;
+  }
   return want >= 2 ? (int)want : 0;
 }
 
@@ -842,9 +852,10 @@ int finalize_problem(mhx_engine* e) {
         const int64_t fit = trim_slices(nwin_all, std::min<int64_t>(slices, cap / units - 1));
         const int64_t least = wanted > 0 ? 2 : std::max<int64_t>(2, (3 * slices + 3) / 4);
         // (fewer slices only where an iteration is short enough for the saved launches to
-        // matter: up to 32 windows per slice - 1e6 points, 1024 walkers: x3 500 us against the
-        // two launches' x4 424; 1e5 points, 1024 walkers: x3 55.9 against x4 72.0)
-        const bool short_rounds = fit > 0 && (nwin_all + fit - 1) / fit <= 32;
+        // matter: up to 48 windows per slice - 1e6 points, 1024 walkers: x3, 163 windows each,
+        // 500 us against the two launches' x4 424; 512: x7, 70 each, 226 against x8 223;
+        // 256: x15, 33 each, 106 against x16 121; 1e5 points, 1024 walkers: x3 55.9 against x4 72.0)
+        const bool short_rounds = fit > 0 && (nwin_all + fit - 1) / fit <= 48;
         slices = fit >= least && (fit == slices || short_rounds || wanted > 0) ? fit : 0;
       }
       const bool want = e->tsplit ? wanted != 0 : true;

@@ -315,15 +315,16 @@ def test_split_mode_is_chosen_by_batch_and_dataset_size(mhx):
     # slices of whole windows ("tsplit": about 512 workgroups in the sweep launch) - as ONE
     # persistent launch per portion of iterations where the GPU holds all its workgroups at once
     # with at least three quarters of the default slicing (fewer slices than the default only
-    # up to 32 windows per slice), else as two launches per iteration;
-    # the batch kernels from 256 workgroups on and for short datasets.  (Slices that would stay
+    # up to 48 windows per slice), else as two launches per iteration;
+    # the batch kernels from 256 workgroups on, for short datasets, and where only two or three
+    # slices of a dataset that is not long would be left to two launches.  (Slices that would stay
     # empty are not asked for: 49 windows in 16 slices are 13 slices of 4 windows.)  Shorter datasets only as
     # a persistent launch: per chain where that fits, else tile-sliced from 4 windows on.
     for spec, chains, want in ((s_long, 1, "persistent tsplit x49"), (s_long, 4, "persistent tsplit x49"),
                                (s_mid, 1, "persistent split x4"),
                                (s_long, 16, "persistent tsplit x49"), (s_long, 256, "persistent tsplit x13"),
                                (s_long, 512, "persistent tsplit x7"), (s_long, 1024, "persistent tsplit x3"),
-                               (s_1e6, 1024, " tsplit x4"), (s_long, 1536, " tsplit x2"),
+                               (s_1e6, 1024, " tsplit x4"), (s_1e6, 256, "persistent tsplit x15"), (s_long, 1536, None), (s_1e6, 1536, " tsplit x2"),
                                (s_long, 2048, None), (s_short, 1, None), (s_short, 64, None),
                                (s_mid, 32, "persistent split x4"), (s_mid, 256, "persistent tsplit x10"),
                                (s_mid, 1024, "persistent tsplit x3"), (s_mid, 1536, None),
