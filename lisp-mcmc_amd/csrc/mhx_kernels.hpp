@@ -1842,11 +1842,8 @@ __device__ __forceinline__ int64_t floor_mod(int64_t a, int64_t b) {
   return m < 0 ? m + b : m;
 }
 // The loop index modulo 200, 1000 and 2 sts, carried along instead of divided out: three 64-bit
-// divisions per iteration are a tenth of a microsecond each on the path a persistent kernel's
-// sweep workgroups wait on (-3 %), and show in the batch kernels where iterations are short
-// (same box: test.lisp's single walker +2.7 %, the driver's window of config 2 +1.1 %; config 3
-// and config 2 after the tick -0.5 %).  The two-launch split step, one iteration per launch,
-// divides as before.
+// divisions per iteration are nothing beside a sweep of the batch kernels, but a tenth of a
+// microsecond each on the path a persistent kernel's sweep workgroups wait on.
 struct LoopPhases {
   int m200, m1000;
   int64_t msts;
@@ -1900,8 +1897,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
   r.status = MHX_CHAIN_DONE;
   if (valid) chain_load(S, c, d, r);
   LoopPhases ph = {0, 0, 0};
-  constexpr bool kPhases = PERSIST || !SPLIT;
-  if (kPhases && valid) ph.set(r.loop_i, R.sts);
+  if (PERSIST && valid) ph.set(r.loop_i, R.sts);
   (void)ph;
   const bool cur_in_lds = d <= kCurParams;
   if (valid && cur_in_lds && lane_id() < d) lds.cur[w][lane_id()] = S.theta[c * d + lane_id()];
@@ -2024,7 +2020,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
         // M:905-917
         bool shut = !r.shutting && (R.n - r.loop_i) < R.tail;
         if (!shut && R.auto_mode && !r.shutting &&
-            (kPhases ? ph.m1000 == 0 : floor_mod(r.loop_i, 1000) == 0) && r.loop_i > 2 * R.sts) {
+            (PERSIST ? ph.m1000 == 0 : floor_mod(r.loop_i, 1000) == 0) && r.loop_i > 2 * R.sts) {
           __threadfence();
           ring.nh = r.nh;
           ring.length = r.length;
@@ -2038,7 +2034,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
           r.T = 1.0;
           r.shutting = 1;
           r.loop_i = R.n - R.tail;
-          if constexpr (kPhases) ph.set(r.loop_i, R.sts);
+          if constexpr (PERSIST) ph.set(r.loop_i, R.sts);
         }
       }
       // M:918 walker-take-step: proposal
@@ -2198,8 +2194,8 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     }
     // regular l-matrix updating M:929-942
     if (i > 0) {
-      const bool m200 = kPhases ? ph.m200 == 0 : floor_mod(i, 200) == 0;
-      const bool msts = !r.shutting && (kPhases ? ph.msts == 0 : floor_mod(i, 2 * R.sts) == 0);
+      const bool m200 = PERSIST ? ph.m200 == 0 : floor_mod(i, 200) == 0;
+      const bool msts = !r.shutting && (PERSIST ? ph.msts == 0 : floor_mod(i, 2 * R.sts) == 0);
       if (m200 || msts) {
         l_stale = true;  // (PERSIST: the factor may change below)
         __threadfence();
@@ -2243,7 +2239,7 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     MHX_TIMC(lds, 6);
     if (r.status == MHX_CHAIN_RUNNING) {
       r.loop_i++;
-      if constexpr (kPhases) ph.step(R.sts);
+      if constexpr (PERSIST) ph.step(R.sts);
     }
   }
 #ifdef MHX_PERSIST_TIMING
