@@ -1843,7 +1843,9 @@ __device__ __forceinline__ int64_t floor_mod(int64_t a, int64_t b) {
 }
 // The loop index modulo 200, 1000 and 2 sts, carried along instead of divided out: three 64-bit
 // divisions per iteration are nothing beside a sweep of the batch kernels, but a tenth of a
-// microsecond each on the path a persistent kernel's sweep workgroups wait on.
+// microsecond each on the path a persistent kernel's sweep workgroups wait on.  (Tried in the
+// batch kernels too: test.lisp's single walker +2.7 %, the driver's window +1 %, but four more
+// live scalars across the sweep cost config 3 and config 4 16 B of scratch each and 0.5-1 %.)
 struct LoopPhases {
   int m200, m1000;
   int64_t msts;
