@@ -198,6 +198,17 @@ def effective_cores():
     return n, info
 
 
+def kernel_label(name):
+    """which stepping kernel serves an engine of that mhx_kernel_name"""
+    if "persistent tsplit" in name:
+        return "k_persist_ts @ " + name
+    if "persistent split" in name:
+        return "k_persist @ " + name
+    if "split x" in name:
+        return "k_split_step + sweep @ " + name
+    return "k_adaptive @ " + name
+
+
 class Fleet:
     """the engines of one benchmark process behind one set of calls: an Engine (one GPU) or a
     Group (mhx_group_*: one host process, several GPUs)"""
@@ -563,7 +574,7 @@ def main():
                    "clock_spin": ("%.0f ms of the same kernel on a throw-away engine %s" % (
                        spin_ms, "between the walk's warm-up launch and its timed launch"
                        if variant == "2" else "before the walk's warm-up launch")) if spin_ms else "none",
-                   "kernel": "k_adaptive @ " + fleet.kernel_name()},
+                   "kernel": kernel_label(fleet.kernel_name())},
         "build": {"id": build_id},
         "roofline": roof,
     }
