@@ -827,7 +827,6 @@ int finalize_problem(mhx_engine* e) {
     // (MHX_NO_PERSIST=1: the two launches per iteration of rounds 1-3)
     e->persist = false;
     if (e->split_slices > 0) {
-      const char* np_ = getenv("MHX_NO_PERSIST");
       const int64_t W = e->fam->waves_per_group;
       // tile-sliced: (1 + slices) workgroups per chain GROUP - with fewer slices, down to 2,
       // where the default slicing would not fit the GPU at once (a run's repacking keeps to the
@@ -861,7 +860,6 @@ int finalize_problem(mhx_engine* e) {
       const bool want = e->tsplit ? wanted != 0 : true;
       e->persist = want && persist_allowed(e) && slices >= (e->tsplit ? 2 : 1) &&
                    units * (1 + slices) <= cap;
-      (void)np_;
       if (e->persist && e->tsplit) {  // (the table of the persistent form: fewer slices, resident windows)
         const int rc = build_ts_table(e, (int)slices);
         if (rc != MHX_OK) return rc;

@@ -1928,7 +1928,6 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
   if constexpr (PERSIST) MHX_PERSIST_PRIO(3);  // (a master's controller: see persist_poll)
 #ifdef MHX_PERSIST_TIMING
   unsigned long long pt_ctrl = 0, pt_wait = 0, pt_n = 0, pt_last = __builtin_readcyclecounter();
-  const unsigned long long pt_rt0 = __builtin_amdgcn_s_memrealtime(), pt_c0 = pt_last;
 #endif
   bool have_pre = false, have_lz = false, l_stale = true, stop_sent = false, early = false;
   (void)early;
@@ -2246,7 +2245,6 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
   }
 #ifdef MHX_PERSIST_TIMING
   if (PERSIST && w == 0 && l == 0 && pt_n) persist_trace(pt_ctrl, pt_wait, 0, pt_n);
-  (void)pt_rt0; (void)pt_c0;
 #endif
   if (valid) {
     if (r.status == MHX_CHAIN_RUNNING && r.loop_i >= R.n) r.status = MHX_CHAIN_DONE;
@@ -2480,7 +2478,6 @@ __device__ __forceinline__ void k_persist_body(const ProblemDesc* __restrict__ P
     const bool free_run = P.K == 1 && slices[slice].solo != 0 && slices[slice].n_tiles > 0;
 #ifdef MHX_PERSIST_TIMING  // (measurement build: where a sweep workgroup's round goes)
     unsigned long long t_poll = 0, t_vote = 0, t_sweep = 0, t0 = __builtin_readcyclecounter(), rounds = 0;
-    unsigned long long s_poll = 0, s_vote = 0, s_sweep = 0;
 #define MHX_PT(acc) do { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - t0; t0 = n_; } while (0)
 #else
 #define MHX_PT(acc) do { } while (0)
@@ -2507,7 +2504,6 @@ __device__ __forceinline__ void k_persist_body(const ProblemDesc* __restrict__ P
       MHX_PT(t_vote);
 #ifdef MHX_PERSIST_TIMING
       if (!any && threadIdx.x == 0) persist_trace(t_poll, t_vote, t_sweep, rounds);
-      (void)s_poll; (void)s_vote; (void)s_sweep;
 #ifdef MHX_X_TIMING
       if (!any && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0 && rounds)
         printf("sweep wg (1,0) wave 0, MHX_TIM phases 0-7, cycles per round: %llu %llu %llu %llu %llu %llu %llu %llu\n",
