@@ -655,6 +655,38 @@ def main():
             "dispatches": [pw_warm, pw_warm + pk["launches"]],   # among mhx_user_adaptive's
             "ratio_to_value": out["value"] / out["value_piecewise"]}
         pw.close()
+    # ... and the same walk with EXACT EARLY REJECTION (MHX_EARLY_REJECT=1; csrc/mhx_kernels.hpp,
+    # sweep()): a sweep ends where the growing sum of squares has already lost the accept test.  The
+    # chains are the same chains bit for bit (tests/test_gpu_early_reject.py); what changes is the
+    # time of iterations that reject - all of a walk's first dozens (T = 10, diag(theta) steps),
+    # hardly any of a settled walk's.  Opt-in and reported BESIDE the headline, whose sweeps are
+    # complete: this figure counts rejections, not sweeps.
+    if (rank == 0 and not per_rank and n_gpus == 1 and not args.no_direct and args.workload == "c2"):
+        os.environ["MHX_EARLY_REJECT"] = "1"
+        try:
+            er = make()
+            er_name = er.kernel_name()  # (finalised - compiled - under the setting)
+        finally:
+            os.environ.pop("MHX_EARLY_REJECT", None)
+        er.start(th0, n_adapt, l0)
+        for _ in range(w_n):
+            er.advance(w_per)
+        er.timing(reset=True)
+        e0 = er.steps()
+        sync()
+        te0 = time.perf_counter()
+        for _ in range(n_launch):
+            er.advance(per_launch)
+        sync()
+        te = time.perf_counter() - te0
+        ek = er.timing()[0]
+        out["value_early_reject"] = (er.steps() - e0) / te
+        out["early_reject"] = {
+            "what": "the same walk, MHX_EARLY_REJECT=1: sweeps end where the partial sum of squares has lost "
+                    "the accept test (exact: same chains bit for bit; a run-time compiled kernel)",
+            "kernel_ms_per_launch": ek["avg_ms"], "kernel": "mhx_user_adaptive @ " + er_name,
+            "ratio_to_value": out["value_early_reject"] / out["value"]}
+        er.close()
     # ... and the reference's own way of working: ONE walker (and a small batch of 64) on the same
     # data.  Too few chains for the batch kernel: the likelihood sum is spread over sweep
     # workgroups and a whole portion of iterations runs as one persistent launch (k_persist_ts;

@@ -735,10 +735,25 @@ int finalize_problem(mhx_engine* e) {
     if (!can) f.tgh = nullptr;  // (nobody would read it: the direct form everywhere, as before)
     any_wgrid = any_wgrid || can;
   }
-  const int aot = (any_expr || any_wgrid) ? SPEC_GENERIC : select_spec(e->P);
+  // MHX_EARLY_REJECT=1: sweep()'s exact early rejection (mhx_kernels.hpp) for a problem of ONE
+  // function of a bounded enumerated model (peaks, polynomial: no term of theirs overflows at
+  // finite parameters) with the weighted normal likelihood and no prior body - compiled at run
+  // time too, so that the ahead-of-time kernels do not carry the test (4-5 % in a walk's first
+  // iterations even when it never fires)
+  bool any_er = false;
+  {
+    const char* er = getenv("MHX_EARLY_REJECT");
+    const FnDesc& f0 = e->P.fn[0];
+    any_er = er && atoi(er) != 0 && specialise && e->P.K == 1 && f0.lik == MHX_LIK_NORMAL &&
+             (f0.model == MHX_MODEL_GAUSS_PEAKS || f0.model == MHX_MODEL_LORENTZ_PEAKS ||
+              f0.model == MHX_MODEL_POLY) &&
+             e->prior_expr[0].expr.empty() && !builtin_model_type(f0).empty() &&
+             e->cfg.adapt_mode != MHX_ADAPT_POOLED;
+  }
+  const int aot = (any_expr || any_wgrid || any_er) ? SPEC_GENERIC : select_spec(e->P);
   e->rtc_note.clear();
   HIP_TRY(hipMemcpy(e->dP.p, &e->P, sizeof(ProblemDesc), hipMemcpyHostToDevice));
-  if (!any_expr && !any_wgrid && (aot != SPEC_GENERIC || !specialise)) {
+  if (!any_expr && !any_wgrid && !any_er && (aot != SPEC_GENERIC || !specialise)) {
     e->spec = force_generic ? SPEC_GENERIC : aot;
     e->user_prog.reset();
   } else {
@@ -759,6 +774,7 @@ int finalize_problem(mhx_engine* e) {
           u.builtin = type;
           u.lik = f.lik;
           u.wgrid = f.tgh != nullptr;
+          u.early_reject = any_er;
           models.push_back(u);
         } else {
           builtin = true;  // stays with the generic dispatcher inside the compiled kernels
@@ -894,7 +910,8 @@ int finalize_problem(mhx_engine* e) {
     for (int k = 0; k < e->P.K; ++k) {
       const FnDesc& f = e->P.fn[k];
       const std::string t = f.model == MHX_MODEL_EXPR ? std::string("expr")
-                            : (f.user_slot >= 0 ? builtin_model_type(f) + (f.tgh ? "+wgrid" : "")
+                            : (f.user_slot >= 0 ? builtin_model_type(f) + (f.tgh ? "+wgrid" : "") +
+                                                      (any_er ? "+early-reject" : "")
                                                 : std::string("generic"));
       e->kernel_name += (k ? ", " : "") + t + ":" + kLik[f.lik & 3];
     }

@@ -70,6 +70,10 @@ __device__ __forceinline__ void lds_tables_begin() {
 __device__ __forceinline__ void lds_begin(GroupLds& lds) {
   if (threadIdx.x == 0) lds.resident = 0;
   if (threadIdx.x == 0) lds.deal_skip = 0;
+#ifdef MHX_EARLY_REJECT  // (a run-time compiled program only: see sweep())
+  if (threadIdx.x < kWavesPerGroup) lds.deal_ll[threadIdx.x] = __builtin_inf();  // no threshold
+  if (threadIdx.x < 2) lds.deal_cost[threadIdx.x] = 0;                           // "somebody is still in"
+#endif
   if (threadIdx.x < 4) lds.vote[threadIdx.x] = 0;
   lds_tables_begin();
   __syncthreads();
@@ -396,6 +400,19 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
   const int w = wave_in_group();
   const int64_t nt = f.n_tiles;
   double acc0 = 0.0, acc1 = 0.0;
+#ifdef MHX_EARLY_REJECT
+  // EXACT EARLY REJECTION (programs compiled at run time with -DMHX_EARLY_REJECT: the engine asks
+  // for it under MHX_EARLY_REJECT=1 for one function of a bounded enumerated model with the
+  // weighted normal likelihood and no prior body).  The sum of squares only grows - every lane's
+  // accumulator and the butterfly are monotone in floating point too - and the accept test is a
+  // threshold on it that the controller knows before the sweep (lds.deal_ll[w]; +inf: none).
+  // After windows 0, 1, 3, 7, 15, 31, 63 a wave whose partial sum is over it leaves the sweep
+  // (it goes on as a wave without a running chain: barriers and DMA only) and says so
+  // (deal_ll[w] = -inf); when no wave of the workgroup is left the sweep ends.  A walk's first
+  // iterations (T = 10, diag(theta) steps) accept nothing, and lose within one to eight windows.
+  bool er_lost = false;
+  int er_i = 0;
+#endif
   // (Poisson) a constant of tlog() pinned in a VGPR - and only there: the pin cannot be optimised
   // away, and the other kernels have better uses for the register
   const double log_a3 = LIK == MHX_LIK_POISSON ? tlog_a3() : kTlogA3;
@@ -789,12 +806,44 @@ __device__ __forceinline__ double sweep(const FnDesc& f, const typename Model::P
     __builtin_amdgcn_s_setprio(0);  // (tile_prio; a short tile may leave its loop at any level)
 #endif
     MHX_TIM(lds, 4);
+#ifdef MHX_EARLY_REJECT
+    bool er_chk = false;
+    if constexpr (LIK == MHX_LIK_NORMAL) {
+      er_chk = !solo && ((wi + 1) & wi) == 0 && wi < 64 && t + kTPW < nt;
+      if (er_chk) {
+        if (active) {
+          const double s_now = wave_sum(acc0 + acc1);
+          // (a non-finite partial sum is never "over": such a proposal is swept to the end and
+          // traps the chain as it always did)
+          if (s_now > *(volatile double*)&lds.deal_ll[w] && s_now < __builtin_inf()) {
+            active = false;
+            er_lost = true;
+          }
+        }
+        if (active && l == 0) lds.deal_cost[er_i & 1] = 1;
+      }
+    }
+#endif
     if (!solo) {  // (a resident tile is never overwritten: nothing to wait for)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of tile t+1 has landed
       __syncthreads();                                   // ... and so has everybody else's
     }
     MHX_TIM(lds, 5);
+#ifdef MHX_EARLY_REJECT
+    if (er_chk) {  // (two flags in turn: the one of the next check is lowered behind this barrier)
+      const int alive = __builtin_amdgcn_readfirstlane(*(volatile int*)&lds.deal_cost[er_i & 1]);
+      if (threadIdx.x == 0) lds.deal_cost[(er_i + 1) & 1] = 0;
+      ++er_i;
+      if (!alive) break;  // every proposal of the workgroup is lost: nothing left to sweep for
+    }
+#endif
   }
+#ifdef MHX_EARLY_REJECT
+  if (er_lost) {
+    if (l == 0) lds.deal_ll[w] = -__builtin_inf();
+    return __builtin_inf();
+  }
+#endif
   return wave_sum(acc0 + acc1);
 }
 
@@ -2101,6 +2150,19 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     double t_next = r.T;
     if (running && !plain && !r.shutting && r.loop_i < R.temp_steps)
       t_next = uniform_f64(R.temps[r.loop_i - R.temps_first]);
+#ifdef MHX_EARLY_REJECT
+    if constexpr (!SPLIT) {
+      // the threshold of sweep()'s early rejection: accept needs lik_const - S/2 + log-prior >
+      // prob0 + T log u, the log-prior of bounds is <= 0 (M:353-369), S only grows
+      double thr = __builtin_inf();
+      const FnDesc& f0 = P.fn[0];
+      if (running && P.K == 1 && f0.lik == MHX_LIK_NORMAL && f0.prior_slot < 0) {
+        const double lim = 2.0 * (f0.lik_const - r.prob0 - r.T * u);
+        thr = lim + 1e-9 * (__builtin_fabs(lim) + __builtin_fabs(f0.lik_const) + __builtin_fabs(r.prob0)) + 1e-6;
+      }
+      if (l == 0) lds.deal_ll[w] = thr;
+    }
+#endif
 #ifndef MHX_NO_PARK  // (build knob for A/B measurements)
     if constexpr (!SPLIT) chain_park(slot, r, u, t_next);
 #endif
@@ -2139,7 +2201,12 @@ __device__ __forceinline__ void k_adaptive_body(const ProblemDesc* __restrict__ 
     // accept decision and every counter of the chain changed under it
     prob1 = uniform_f64(prob1);
     if (!running) continue;
-    if (!finite_f64(prob1)) {
+    bool er_lost = false;
+#ifdef MHX_EARLY_REJECT  // (the sweep left early: -inf stands for "rejected", not for a trap)
+    if constexpr (!SPLIT)
+      er_lost = __builtin_amdgcn_readfirstlane((int)(*(volatile double*)&lds.deal_ll[w] == -__builtin_inf())) != 0;
+#endif
+    if (!finite_f64(prob1) && !er_lost) {
       r.status = MHX_CHAIN_FP_TRAP;
       continue;
     }

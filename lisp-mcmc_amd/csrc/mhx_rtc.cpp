@@ -166,6 +166,9 @@ static std::string generate(const std::vector<UserExpr>& models,
                             const std::vector<UserExpr>& priors, bool builtin_fallback,
                             int min_waves, int threads, bool with_split = false) {
   std::ostringstream s;
+  bool early_reject = false;
+  for (const UserExpr& m : models) early_reject = early_reject || m.early_reject;
+  if (early_reject) s << "#define MHX_EARLY_REJECT 1\n";
   s << "#define MHX_USER_THREADS " << threads << "\n"
     << "#include \"mhx_kernels.hpp\"\n"
        "namespace mhx {\n"

@@ -27,6 +27,8 @@ struct UserExpr {
   int xcols = 1;         // expression models: 2 when the text names xcol1 (a second column of x)
   bool wgrid = false;    // builtin peaks models: the function has a per-window grid table
                          // (FnDesc::tgh) - its kernel is FixedSpec<Model, LIK, true>
+  bool early_reject = false;  // builtin models: compile the program with sweep()'s exact early
+                              // rejection (-DMHX_EARLY_REJECT; mhx_kernels.hpp)
   int lik = -1;          // models: the function's likelihood kind (-1: dispatch at run time)
   std::string lik_expr;  // models with MHX_LIK_EXPR: the per-point term over y, model, error
 };

@@ -35,6 +35,8 @@ def test_bench_line_at_the_drivers_arguments():
     assert r["kernel_ms_per_launch"] * 1e-3 <= d["ms_per_step"] * 1e-3 * 20 * 1.001
     assert d["build"]["id"].startswith("csrc:")
     assert d["value_direct_form"] > 0 and d["direct_form"]["ratio_to_value"] > 1.0
+    er = d["early_reject"]   # (a walk's iterations 6-25 accept nothing: every sweep is left early)
+    assert "+early-reject" in er["kernel"] and d["value_early_reject"] > 1.5 * d["value"], er
     sb = d["small_batches"]
     for k in ("walkers_1", "walkers_64"):   # (one persistent launch per portion: well under the 16-20 us of two launches)
         assert "persistent tsplit" in sb[k]["kernel"] and 0 < sb[k]["us_per_iteration"] < 14 and not sb[k]["trapped"], sb

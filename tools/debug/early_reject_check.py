@@ -1,5 +1,5 @@
 """State of config 2's walk (4096 chains from the bench's start) after 30 and 450 iterations, as a
-digest: run under two libraries (MHX_LIBRARY) and compare the lines."""
+digest: run with and without MHX_EARLY_REJECT=1 and compare the lines."""
 import hashlib, os, sys
 sys.path[:0] = ["/root/repo", "/root/repo/tests"]
 import numpy as np
